@@ -1,0 +1,13 @@
+"""Import shim: the package directory is named ``nerf-simple_amd`` (not a valid
+Python identifier), so ``import nerf_simple_amd`` loads it from there."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "nerf-simple_amd")
+_spec = importlib.util.spec_from_file_location(
+    "nerf_simple_amd", os.path.join(_dir, "__init__.py"),
+    submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["nerf_simple_amd"] = _mod
+_spec.loader.exec_module(_mod)

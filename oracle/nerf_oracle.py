@@ -1,0 +1,236 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+A from-scratch PyTorch-CPU restatement of the reference hot path
+(UCSD-Comp-Imaging/Nerf-Simple), functional style over a plain state dict.
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of
+``bench.py`` may import this module; the shipped render path never does (it
+fails loudly when the HIP library is missing instead of falling back here).
+
+Parity status: PINNED.  Every function below is checked bit-for-bit (same
+torch build, CPU) against outputs of the reference source imported in the
+build container -- fixtures under tests/golden/, produced by
+tests/golden/make_golden.py (which holds no reference code).  The reference
+pins torch==1.11.0 (requirements.txt:2); only torch 2.10.0 exists offline, so
+the goldens are "reference source on torch 2.10 CPU" (SURVEY.md section 8c).
+
+Each function cites the reference file:line it restates.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------
+# positional encoding  (reference utils/xyz.py:6-36)
+# --------------------------------------------------------------------------
+def gamma(x, L=4):
+    """[sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)] along dim 1
+    (utils/xyz.py:6-14).  No pi factor; the |x|>1 warning is not reproduced
+    (it is not part of the results)."""
+    cols = []
+    for i in range(L):
+        cols.append(torch.sin(2 ** i * x))
+        cols.append(torch.cos(2 ** i * x))
+    return torch.cat(cols, dim=1)
+
+
+def positional_encoder(vec, Lp=10, Ld=4):
+    """vec [P,6] -> posx [P,3+6Lp], posd [P,3+6Ld]; grouped per coordinate:
+    [x,y,z, g(x), g(y), g(z)]  (utils/xyz.py:16-36)."""
+    c = [vec[:, i:i + 1] for i in range(6)]
+    posx = torch.cat(c[0:3] + [gamma(c[i], Lp) for i in range(3)], dim=1)
+    posd = torch.cat(c[3:6] + [gamma(c[i], Ld) for i in range(3, 6)], dim=1)
+    return posx, posd
+
+
+# --------------------------------------------------------------------------
+# the MLP  (reference utils/nets.py:8-43)
+# --------------------------------------------------------------------------
+def nerf_forward(sd, v, Lp=10, Ld=4, return_hidden=False):
+    """v [P,6] -> [P,4] = [r,g,b (raw, no sigmoid), sigma (raw)].
+
+    Data-flow of utils/nets.py:34-43: five ReLU'd layers, skip-concat [h ; x]
+    (h first), two more ReLU'd layers, sigma head on the post-ReLU features,
+    a linear 256->256 WITHOUT activation, colour head on [h ; d]."""
+    x, d = positional_encoder(v, Lp, Ld)
+    h = x
+    for i in (0, 2, 4, 6, 8):
+        h = F.relu(F.linear(h, sd[f"layers_0.{i}.weight"], sd[f"layers_0.{i}.bias"]))
+    h5 = h
+    h = F.relu(F.linear(torch.cat([h, x], dim=1),
+                        sd["skip_conn_layer.0.weight"], sd["skip_conn_layer.0.bias"]))
+    for i in (0, 2):
+        h = F.relu(F.linear(h, sd[f"layers_1.{i}.weight"], sd[f"layers_1.{i}.bias"]))
+    h8 = h
+    sigma = F.linear(h8, sd["sigma_fc.0.weight"], sd["sigma_fc.0.bias"])
+    h9 = F.linear(h8, sd["layers_2.weight"], sd["layers_2.bias"])
+    c = F.relu(F.linear(torch.cat([h9, d], dim=1),
+                        sd["color_fc.0.weight"], sd["color_fc.0.bias"]))
+    rgb = F.linear(c, sd["color_fc.2.weight"], sd["color_fc.2.bias"])
+    out = torch.cat([rgb, sigma], dim=1)
+    if return_hidden:
+        return out, {"h5": h5, "h8": h8, "h9": h9}
+    return out
+
+
+# --------------------------------------------------------------------------
+# sampling + compositing  (reference utils/rendering.py:13-85)
+# --------------------------------------------------------------------------
+def sample_ts(u, tn=2, tf=6):
+    """Stratified sample positions from jitter u [B,N] in [0,1)
+    (utils/rendering.py:25-29): ts = (t_bins[1]-t_bins[0]) * u + t_bins[:-1]."""
+    N = u.shape[1]
+    t_bins = torch.linspace(tn, tf, N + 1)
+    return (t_bins[1] - t_bins[0]) * u + t_bins[:-1]
+
+
+def query_points(rays, ts):
+    """rays [B,6], ts [B,N] -> (query_pts [B*N,6], unit dirs [B,3])
+    (utils/rendering.py:31-40).  Positions use the UN-normalised direction;
+    the network input and the compositor get the normalised one."""
+    o, d = rays[:, :3], rays[:, 3:]
+    N = ts.shape[1]
+    locs = o.unsqueeze(-1) + d.unsqueeze(-1) * ts.unsqueeze(1)       # [B,3,N]
+    dn = d / torch.norm(d, dim=1, keepdim=True)
+    q = torch.cat((locs, dn.unsqueeze(-1).expand(-1, -1, N)), dim=1)  # [B,6,N]
+    return q.permute(0, 2, 1).reshape(-1, 6), dn
+
+
+def volume_render(nerf_outs, ts, dirs):
+    """nerf_outs [B,N,4], ts [B,N], dirs [B,3] -> (rgb, disp, alpha, acc, w)
+    (utils/rendering.py:47-85).  softplus(beta=1, threshold=20); last delta
+    1e10; transmittance = exclusive cumprod of (1 - alpha + 1e-10); the second
+    output is DISPARITY 1/max(1e-10, depth/acc) (NaN when acc == 0)."""
+    deltas = ts[:, 1:] - ts[:, :-1]
+    deltas = torch.cat((deltas, 1e10 * torch.ones_like(deltas[:, :1])), dim=1)
+    deltas = deltas * torch.norm(dirs[..., None, :], dim=-1)
+    sigma = nerf_outs[..., 3]
+    alpha = 1 - torch.exp(-F.softplus(sigma) * deltas)
+    ones = torch.ones((alpha.shape[0], 1))
+    w = alpha * torch.cumprod(torch.cat([ones, 1. - alpha + 1e-10], -1), -1)[:, :-1]
+    rgb = torch.sum(w.unsqueeze(-1) * nerf_outs[..., :3], dim=1)
+    depth = torch.sum(w * ts, dim=-1)
+    acc = torch.sum(w, dim=-1)
+    disp = torch.max(1e-10 * torch.ones_like(depth), depth / torch.sum(w, dim=-1))
+    disp = 1. / disp
+    return rgb, disp, alpha, acc, w
+
+
+def render_nerf(rays, sd, N, tn=2, tf=6, u=None, ts=None):
+    """The reference render_nerf(rays, net, N, tn, tf) (utils/rendering.py:13-45)
+    with the net given as a state dict.  ``u`` [B,N]: explicit jitter; when
+    both u and ts are None one torch.rand(B,N) is drawn from the CPU default
+    generator exactly as the reference does (:28)."""
+    B = rays.shape[0]
+    if ts is None:
+        if u is None:
+            u = torch.rand(B, N)
+        ts = sample_ts(u, tn, tf)
+    q, dn = query_points(rays, ts)
+    out = nerf_forward(sd, q).reshape(B, N, 4)
+    return volume_render(out, ts, dn)
+
+
+# --------------------------------------------------------------------------
+# cameras  (reference utils/xyz.py:38-91, utils/rendering.py:129-134)
+# --------------------------------------------------------------------------
+def rays_single_cam(cam_params):
+    """[H,W,f] -> camera-frame directions [3, H*W], row-major h*W+w:
+    dir(h,w) = ((w - W//2)/f, -(h - H//2)/f, -1)  (utils/xyz.py:38-52)."""
+    H, W, f = cam_params
+    hh = (torch.arange(H) - H // 2).reshape(H, 1).expand(H, W)
+    ww = (torch.arange(W) - W // 2).reshape(1, W).expand(H, W)
+    d = torch.stack((ww / f, -hh / f, -torch.ones_like(ww))).float()
+    return d.reshape(3, -1)
+
+
+def spherical_to_pose(r, theta, phi):
+    """Camera-to-world 4x4 for spherical (r, theta deg, phi deg):
+    Rz(phi) . Rx(theta) . T(0,0,r)   (utils/xyz.py:55-81)."""
+    th, ph = np.radians(theta), np.radians(phi)
+    T = np.eye(4)
+    T[2, 3] = r
+    Rt = np.array([[1, 0, 0, 0],
+                   [0, np.cos(th), np.sin(th), 0],
+                   [0, -np.sin(th), np.cos(th), 0],
+                   [0, 0, 0, 1.]])
+    Rp = np.array([[np.cos(ph), np.sin(ph), 0, 0],
+                   [-np.sin(ph), np.cos(ph), 0, 0],
+                   [0, 0, 1, 0],
+                   [0, 0, 0, 1.]])
+    return Rp @ Rt @ T
+
+
+def poses_to_render(r, theta, n_phi=40):
+    """n_phi poses on a circle of azimuths linspace(0,360,n_phi) (utils/xyz.py:83-91)."""
+    return [torch.from_numpy(spherical_to_pose(r, theta, p)).float()
+            for p in np.linspace(0, 360.0, n_phi)]
+
+
+def camera_rays(pose, cam_params):
+    """pose [4,4] float32 tensor -> rays [H*W,6] = [origin, R @ dir]
+    (utils/rendering.py:129-134)."""
+    d = rays_single_cam(cam_params)
+    rd = torch.matmul(pose[:3, :3], d)                      # [3,HW]
+    o = pose[:3, 3:].expand(3, d.shape[1])
+    return torch.cat((o, rd), dim=0).permute(1, 0).reshape(-1, 6)
+
+
+def render_image(sd, rays, batch_size, N=128, tn=2, tf=6, u=None):
+    """Batched full-image render with the reference's caller semantics
+    (utils/rendering.py:139-151): per batch render_nerf, clip rgb to [0,1]
+    AFTER compositing, disparity un-clipped.  Unlike the reference the tail
+    batch is rendered too.  ``u`` [B,N] optional explicit jitter; otherwise one
+    torch.rand(batch,N) per batch in batch order."""
+    rgbs, disps = [], []
+    with torch.no_grad():
+        for s in range(0, rays.shape[0], batch_size):
+            r = rays[s:s + batch_size]
+            ub = None if u is None else u[s:s + batch_size]
+            rgb, disp, _, _, _ = render_nerf(r, sd, N, tn, tf, u=ub)
+            rgbs.append(torch.clip(rgb, 0., 1.))
+            disps.append(disp)
+    return torch.cat(rgbs), torch.cat(disps)
+
+
+# --------------------------------------------------------------------------
+# loss / PSNR / one optimizer step  (reference train.py:16-26, 41-57)
+# --------------------------------------------------------------------------
+def img_mse(gt, pred):
+    return torch.mean((pred - gt) ** 2)
+
+
+def img_psnr(gt, pred):
+    """20 log10(max(gt)) - 10 log10(mse): peak is max(gt), not 1 (train.py:21-26)."""
+    ten = torch.tensor(10)
+    return 20 * torch.log(torch.max(gt)) / torch.log(ten) \
+        - 10 * torch.log(img_mse(gt, pred)) / torch.log(ten)
+
+
+def train_step_grads(sd, rays, u, gt, N, tn=2, tf=6):
+    """loss = MSELoss(rgb, gt) (mean over B*3) and d loss / d every parameter
+    for fixed (rays, u, gt)  (train.py:51-54)."""
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    rgb, _, _, _, _ = render_nerf(rays, params, N, tn, tf, u=u)
+    loss = F.mse_loss(rgb, gt)
+    loss.backward()
+    return loss.detach(), {k: p.grad.detach() for k, p in params.items()}
+
+
+def adam_step(sd, grads, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, step=1, state=None):
+    """torch.optim.Adam defaults (train.py:43,55), restated explicitly.
+    Returns (new_sd, new_state)."""
+    b1, b2 = betas
+    new_sd, new_state = {}, {}
+    for k, p in sd.items():
+        g = grads[k]
+        m, v = (state[k] if state is not None else (torch.zeros_like(p), torch.zeros_like(p)))
+        m = b1 * m + (1 - b1) * g
+        v = b2 * v + (1 - b2) * g * g
+        mhat = m / (1 - b1 ** step)
+        denom = (v.sqrt() / math.sqrt(1 - b2 ** step)) + eps
+        new_sd[k] = p - lr * mhat / denom
+        new_state[k] = (m, v)
+    return new_sd, new_state
