@@ -1,0 +1,120 @@
+/* nerf_amd.h -- C ABI of libnerf_amd.so: the MI355X (gfx950) NeRF render hot path.
+ *
+ * Drop-in boundary for the hot path of UCSD-Comp-Imaging/Nerf-Simple.  The
+ * reference has no FFI; its boundary is plain Python call signatures in
+ * package `utils`.  Each entry point below names the
+ * reference function (file:line, relative to the reference repo) whose body it
+ * replaces; the Python host side (nerf-simple_amd/utils/) keeps the reference's
+ * names, argument order, defaults and return order and calls these through
+ * ctypes (binding shown in INTEGRATION.md).
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer unless its name starts with `h_`;
+ *     fp32, row-major, contiguous; never written unless documented as output;
+ *   - the library allocates nothing, frees nothing and keeps no pointer after
+ *     return; workspaces are caller-provided;
+ *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it,
+ *     do no host synchronisation and are safe to capture into a hipGraph;
+ *   - return value: 0 = launched, otherwise a negative NERF_AMD_E* code or a
+ *     positive hipError_t; nothing throws or exits across the ABI.
+ */
+#ifndef NERF_AMD_H
+#define NERF_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NERF_AMD_ABI_VERSION 1
+
+/* error codes */
+#define NERF_AMD_EINVAL   (-1)   /* bad argument (null pointer, negative size, ...) */
+#define NERF_AMD_EUNSUP   (-2)   /* unsupported configuration */
+
+/* precision of the fused MLP */
+#define NERF_AMD_F32   0   /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32), fp32 end to end */
+#define NERF_AMD_BF16  1   /* bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+
+/* flags of nerf_amd_render_forward / nerf_amd_mlp_forward_rays */
+#define NERF_AMD_TS_GIVEN   1u  /* `u` holds sample positions ts[B,N], not jitter */
+#define NERF_AMD_DEVICE_RNG 2u  /* `u` ignored (may be NULL): jitter from the counter RNG */
+
+/* ---- introspection (host only, no GPU needed) ------------------------------ */
+int      nerf_amd_abi_version(void);
+/* 595844 = parameters of Nerf(Lp=10, Ld=4, H=256), reference utils/nets.py:9-32 */
+int64_t  nerf_amd_param_count(void);
+/* bytes of the packed weight image for a precision (the caller allocates it) */
+int64_t  nerf_amd_packed_bytes(int precision);
+/* bytes of workspace nerf_amd_render_forward needs for B rays x N samples */
+int64_t  nerf_amd_render_workspace_bytes(int64_t B, int N);
+/* host-side self-check of the packed-weight index math (bijectivity of the
+ * k-permutations, offsets, sizes); 0 = consistent.  Used by the CPU tests. */
+int      nerf_amd_layout_selfcheck(void);
+/* host-side: source column (or -1 = padding) that the packed bf16/f32 image
+ * holds at (layer, k-step, lane-half, element); lets tests audit the packing. */
+int      nerf_amd_layout_src_col(int precision, int layer, int kstep, int half, int elem);
+
+/* ---- weights ---------------------------------------------------------------- */
+/* Pack the 24 state-dict tensors of the reference Nerf (utils/nets.py:16-32),
+ * given flattened in state_dict order as one fp32 vector `params`[595844], into
+ * the MFMA-fragment-ordered image the fused kernels stream.  Derived cache:
+ * re-run after any parameter update.  */
+int nerf_amd_pack_weights(const float* params, void* packed, int precision, void* stream);
+
+/* ---- positional encoding: utils/xyz.py:6-36 --------------------------------- */
+/* gamma(x, L): x[n] -> out[n, 2L] = [sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]
+ * (utils/xyz.py:6-14).  `x_stride` in floats lets x be a column of a wider table. */
+int nerf_amd_gamma(const float* x, int64_t x_stride, float* out, int64_t n, int L, void* stream);
+/* positional_encoder(vec, Lp, Ld): vec[P,6] -> posx[P,3+6Lp], posd[P,3+6Ld]
+ * (utils/xyz.py:16-36), columns grouped per coordinate. */
+int nerf_amd_positional_encoder(const float* vec, float* posx, float* posd,
+                                int64_t P, int Lp, int Ld, void* stream);
+
+/* ---- the MLP: Nerf.forward, utils/nets.py:34-43 ------------------------------ */
+/* pts[P,6] = [x,y,z,d1,d2,d3] -> out[P,4] = [r,g,b,sigma] (raw: no sigmoid, no
+ * softplus).  Encoding + 12 dense layers fused in one kernel; activations never
+ * leave the CU.  `packed` from nerf_amd_pack_weights with the same precision. */
+int nerf_amd_mlp_forward(const float* pts, const void* packed, float* out,
+                         int64_t P, int precision, void* stream);
+
+/* ---- compositing: volume_render, utils/rendering.py:47-85 -------------------- */
+/* raw[B,N,4], ts[B,N], dirs[B] (3 floats at stride `dirs_stride` floats) ->
+ * rgb[B,3], disp[B], alpha[B,N], acc[B], w[B,N].  alpha and w may be NULL.
+ * One wavefront per ray; transmittance by a wave-level product scan. */
+int nerf_amd_volume_render(const float* raw, const float* ts,
+                           const float* dirs, int64_t dirs_stride,
+                           float* rgb, float* disp, float* alpha, float* acc, float* w,
+                           int64_t B, int N, void* stream);
+
+/* ---- the whole path: render_nerf, utils/rendering.py:13-45 ------------------- */
+/* rays[B,6] = [origin, direction] -> (rgb[B,3], disp[B], alpha[B,N], acc[B], w[B,N]).
+ *   u        jitter in [0,1) [B,N] exactly as the reference draws it with
+ *            torch.rand(B,N) (utils/rendering.py:28); or ts[B,N] with
+ *            NERF_AMD_TS_GIVEN; or unused with NERF_AMD_DEVICE_RNG (counter RNG
+ *            keyed by (seed, ray_id0 + ray, sample) so results do not depend on
+ *            batching or sharding).
+ *   tbins    linspace(tn, tf, N+1) computed by the caller [N+1] (device), so
+ *            bin edges are bit-identical to torch.linspace (utils/rendering.py:25)
+ *   alpha,w  optional (NULL to skip the 8 B/sample of output traffic)
+ *   workspace  nerf_amd_render_workspace_bytes(B,N) bytes, 256-B aligned       */
+int nerf_amd_render_forward(const float* rays, const float* u, const float* tbins,
+                            const void* packed, int precision, uint32_t flags,
+                            uint64_t seed, int64_t ray_id0,
+                            float* rgb, float* disp, float* alpha, float* acc, float* w,
+                            void* workspace, int64_t B, int N, void* stream);
+
+/* Stage 1 of the above on its own (sampling + encoding + MLP): writes
+ * raw[B,N,4] and ts[B,N].  Exposed for the importance-sampling caller, which
+ * needs explicit ts. */
+int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tbins,
+                              const void* packed, int precision, uint32_t flags,
+                              uint64_t seed, int64_t ray_id0,
+                              float* raw, float* ts, int64_t B, int N, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERF_AMD_H */

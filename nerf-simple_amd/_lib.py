@@ -1,0 +1,100 @@
+"""ctypes binding of libnerf_amd.so (C ABI: include/nerf_amd.h).
+
+There is deliberately NO fallback: if the shared library is missing or a call
+fails, a RuntimeError is raised.  The library is built in-tree by
+``make -C nerf-simple_amd/csrc`` (or ``__graft_entry__.build()``).
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
+
+F32, BF16 = 0, 1
+FLAG_TS_GIVEN, FLAG_DEVICE_RNG = 1, 2
+_PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, F32: F32,
+               "bf16": BF16, "bfloat16": BF16, BF16: BF16}
+
+_lib = None
+_lock = threading.Lock()
+
+_vp, _i64, _i32, _u32, _u64 = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                               ctypes.c_uint32, ctypes.c_uint64)
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "nerf_amd_abi_version": (_i32, []),
+    "nerf_amd_param_count": (_i64, []),
+    "nerf_amd_packed_bytes": (_i64, [_i32]),
+    "nerf_amd_render_workspace_bytes": (_i64, [_i64, _i32]),
+    "nerf_amd_layout_selfcheck": (_i32, []),
+    "nerf_amd_layout_src_col": (_i32, [_i32, _i32, _i32, _i32, _i32]),
+    "nerf_amd_pack_weights": (_i32, [_vp, _vp, _i32, _vp]),
+    "nerf_amd_gamma": (_i32, [_vp, _i64, _vp, _i64, _i32, _vp]),
+    "nerf_amd_positional_encoder": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "nerf_amd_mlp_forward": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_volume_render": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_render_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _u32, _u64, _i64,
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_mlp_forward_rays": (_i32, [_vp, _vp, _vp, _vp, _i32, _u32, _u64, _i64,
+                                         _vp, _vp, _i64, _i32, _vp]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+
+def precision_code(p):
+    try:
+        return _PRECISIONS[p]
+    except KeyError:
+        raise ValueError(f"precision must be 'fp32' or 'bf16', got {p!r}") from None
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it is not built)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: build the HIP library with "
+                        "`make -C nerf-simple_amd/csrc` (there is no CPU fallback)")
+                h = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in _SIGNATURES.items():
+                    fn = getattr(h, name)          # AttributeError if an export is missing
+                    fn.restype, fn.argtypes = res, args
+                if h.nerf_amd_abi_version() != 1:
+                    raise RuntimeError("libnerf_amd.so ABI version mismatch")
+                _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported configuration"}.get(rc, f"hipError_t {rc}")
+        raise RuntimeError(f"{what} failed: {kind}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda_f32(t, name):
+    """The kernels take fp32, contiguous, device-resident tensors; anything
+    else is an error (the reference's callers do .cuda() themselves,
+    utils/rendering.py:102, train.py:51)."""
+    import torch
+    if not torch.is_tensor(t):
+        raise AssertionError(f"{name} needs to be a torch tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on the GPU (got a {t.device} tensor); "
+                           "this package has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32, got {t.dtype}")
+    return t

@@ -1,0 +1,167 @@
+// api.hip -- the C ABI of libnerf_amd.so (include/nerf_amd.h): argument
+// checking, host-side introspection and the composition of the render path
+// out of the kernels in this directory.  No allocation, no host sync.
+#include "nerf_device.h"
+#include "../../include/nerf_amd.h"
+
+using namespace nerf_layout;
+
+extern "C" {
+int nerf_amd_launch_pack(const float*, void*, int, hipStream_t);
+int nerf_amd_launch_gamma(const float*, long long, float*, long long, int, hipStream_t);
+int nerf_amd_launch_posenc(const float*, float*, float*, long long, int, int, hipStream_t);
+int nerf_amd_launch_composite(const float*, const float*, const float*, long long, float*, float*,
+                              float*, float*, float*, long long, int, int, hipStream_t);
+int nerf_amd_launch_mlp_bf16(const MlpArgs*, int, hipStream_t);
+int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
+}
+
+namespace {
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool bad_precision(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
+inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+int launch_mlp(const MlpArgs& a, int rays_mode, int precision, hipStream_t s) {
+    return precision == NERF_AMD_BF16 ? nerf_amd_launch_mlp_bf16(&a, rays_mode, s)
+                                      : nerf_amd_launch_mlp_f32(&a, rays_mode, s);
+}
+}  // namespace
+
+extern "C" {
+
+int nerf_amd_abi_version(void) { return NERF_AMD_ABI_VERSION; }
+int64_t nerf_amd_param_count(void) { return PARAM_COUNT; }
+
+int64_t nerf_amd_packed_bytes(int precision) {
+    if (bad_precision(precision)) return NERF_AMD_EINVAL;
+    // + slack so that the staging loads of the last chunks stay inside the allocation
+    return (precision == NERF_AMD_BF16 ? BF16_PACKED_BYTES : F32_PACKED_BYTES);
+}
+
+int64_t nerf_amd_render_workspace_bytes(int64_t B, int N) {
+    if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
+    // raw[B,N,4] + ts[B,N]
+    return align_up(B * N * 16, 256) + align_up(B * N * 4, 256);
+}
+
+int nerf_amd_layout_src_col(int precision, int layer, int kstep, int half, int elem) {
+    if (layer < 0 || layer >= NUM_LAYERS) return -2;
+    if (precision == NERF_AMD_BF16) {
+        if (kstep < 0 || kstep >= bf16_ks(layer) || half < 0 || half > 1 || elem < 0 || elem > 7) return -2;
+        return src_col_bf16(layer, kstep, half, elem);
+    }
+    if (precision == NERF_AMD_F32) {
+        if (kstep < 0 || kstep >= f32_ks(layer) || half < 0 || half > 3) return -2;
+        return src_col_f32(layer, kstep, half);
+    }
+    return -2;
+}
+
+// Every source column of every layer must be hit exactly once by the packed
+// k positions (the permutations are bijections onto the true K, padding aside).
+int nerf_amd_layout_selfcheck(void) {
+    static_assert(BF16_WEIGHT_KIB == 1192, "bf16 image size");
+    static_assert(BIAS_FLOATS == 2496, "bias table size");
+    static_assert(F32_NUM_CHUNKS == 154, "f32 chunk count");
+    for (int L = 0; L < NUM_LAYERS; ++L) {
+        const LayerDesc d = layer_desc(L);
+        int seen[320];
+        for (int prec = 0; prec < 2; ++prec) {
+            for (int i = 0; i < 320; ++i) seen[i] = 0;
+            int pads = 0;
+            if (prec == NERF_AMD_BF16) {
+                for (int s = 0; s < bf16_ks(L); ++s)
+                    for (int h = 0; h < 2; ++h)
+                        for (int j = 0; j < 8; ++j) {
+                            const int c = src_col_bf16(L, s, h, j);
+                            if (c < 0) { ++pads; continue; }
+                            if (c >= d.ld) return 100 + L;
+                            ++seen[c];
+                        }
+            } else {
+                for (int s = 0; s < f32_ks(L); ++s)
+                    for (int g = 0; g < 4; ++g) {
+                        const int c = src_col_f32(L, s, g);
+                        if (c < 0) { ++pads; continue; }
+                        if (c >= d.ld) return 200 + L;
+                        ++seen[c];
+                    }
+            }
+            for (int i = 0; i < d.ld; ++i)
+                if (seen[i] != 1) return 300 + 20 * prec + L;
+            if (pads != layer_k(L) - d.ld) return 400 + 20 * prec + L;
+        }
+    }
+    return 0;
+}
+
+int nerf_amd_pack_weights(const float* params, void* packed, int precision, void* stream) {
+    if (!params || !packed || bad_precision(precision)) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_pack(params, packed, precision, S(stream));
+}
+
+int nerf_amd_gamma(const float* x, int64_t x_stride, float* out, int64_t n, int L, void* stream) {
+    if (n < 0 || L < 0 || x_stride < 0) return NERF_AMD_EINVAL;
+    if (n == 0 || L == 0) return 0;
+    if (!x || !out) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_gamma(x, x_stride, out, n, L, S(stream));
+}
+
+int nerf_amd_positional_encoder(const float* vec, float* posx, float* posd, int64_t P, int Lp, int Ld,
+                                void* stream) {
+    if (P < 0 || Lp < 0 || Ld < 0) return NERF_AMD_EINVAL;
+    if (P == 0) return 0;
+    if (!vec || !posx || !posd) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_posenc(vec, posx, posd, P, Lp, Ld, S(stream));
+}
+
+int nerf_amd_mlp_forward(const float* pts, const void* packed, float* out, int64_t P, int precision,
+                         void* stream) {
+    if (P < 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
+    if (P == 0) return 0;
+    if (!pts || !packed || !out) return NERF_AMD_EINVAL;
+    MlpArgs a{};
+    a.pts = pts; a.packed = packed; a.raw = out; a.P = P; a.N = 1;
+    return launch_mlp(a, 0, precision, S(stream));
+}
+
+int nerf_amd_volume_render(const float* raw, const float* ts, const float* dirs, int64_t dirs_stride,
+                           float* rgb, float* disp, float* alpha, float* acc, float* w, int64_t B, int N,
+                           void* stream) {
+    if (B < 0 || N <= 0 || dirs_stride < 3) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (!raw || !ts || !dirs || !rgb || !disp || !acc) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_composite(raw, ts, dirs, dirs_stride, rgb, disp, alpha, acc, w, B, N, 0, S(stream));
+}
+
+int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tbins, const void* packed,
+                              int precision, uint32_t flags, uint64_t seed, int64_t ray_id0, float* raw,
+                              float* ts, int64_t B, int N, void* stream) {
+    if (B < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (!rays || !packed || !raw) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+    MlpArgs a{};
+    a.rays = rays; a.u = u; a.tbins = tbins; a.packed = packed; a.raw = raw; a.ts_out = ts;
+    a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
+    return launch_mlp(a, 1, precision, S(stream));
+}
+
+int nerf_amd_render_forward(const float* rays, const float* u, const float* tbins, const void* packed,
+                            int precision, uint32_t flags, uint64_t seed, int64_t ray_id0, float* rgb,
+                            float* disp, float* alpha, float* acc, float* w, void* workspace, int64_t B,
+                            int N, void* stream) {
+    if (B < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (!workspace || !rgb || !disp || !acc) return NERF_AMD_EINVAL;
+    float* raw = reinterpret_cast<float*>(workspace);
+    float* ts = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up(B * N * 16, 256));
+    int rc = nerf_amd_mlp_forward_rays(rays, u, tbins, packed, precision, flags, seed, ray_id0, raw, ts, B, N,
+                                       stream);
+    if (rc) return rc;
+    // dirs = rays[:,3:] normalised inside the kernel (utils/rendering.py:37,43)
+    return nerf_amd_launch_composite(raw, ts, rays + 3, 6, rgb, disp, alpha, acc, w, B, N, 1, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,78 @@
+// encode.hip -- stand-alone positional encoding kernels, the drop-in bodies of
+// gamma (reference utils/xyz.py:6-14) and positional_encoder (utils/xyz.py:16-36).
+// The fused MLP kernels encode in registers and never call these; they exist
+// for callers that want posx/posd themselves.
+//
+// HBM-bound: 24 B read and (3+6Lp + 3+6Ld)*4 = 360 B written per point.  One
+// thread per OUTPUT element so stores are fully coalesced; the six inputs of a
+// point are re-read through L1/L2.  sin/cos use the accurate ocml sinf/cosf on
+// the exactly-scaled argument 2^i * x (a power-of-two product is exact in fp32,
+// as it is in the reference), so results track torch-CPU to ~1 ulp.
+#include "nerf_device.h"
+
+namespace {
+
+__device__ __forceinline__ float enc_value(float x, int idx) {
+    // idx = 2*level + trig
+    const float a = ldexpf(x, idx >> 1);
+    return (idx & 1) ? cosf(a) : sinf(a);
+}
+
+// out[n, 2L]
+__global__ void gamma_kernel(const float* __restrict__ x, long long x_stride,
+                             float* __restrict__ out, long long n, int L) {
+    const long long total = n * 2 * L;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long p = e / (2 * L);
+        const int idx = (int)(e - p * 2 * L);
+        out[e] = enc_value(x[p * x_stride], idx);
+    }
+}
+
+// one launch writes both tables: columns [0, Cx) -> posx, [Cx, Cx+Cd) -> posd
+__global__ void posenc_kernel(const float* __restrict__ vec, float* __restrict__ posx,
+                              float* __restrict__ posd, long long P, int Lp, int Ld) {
+    const int Cx = 3 + 6 * Lp, Cd = 3 + 6 * Ld, C = Cx + Cd;
+    const long long total = P * C;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long p = e / C;
+        int col = (int)(e - p * C);
+        const float* v = vec + p * 6;
+        float* dst;
+        int L, base;
+        if (col < Cx) { dst = posx + p * Cx + col; L = Lp; base = 0; }
+        else { col -= Cx; dst = posd + p * Cd + col; L = Ld; base = 3; }
+        float r;
+        if (col < 3) {
+            r = v[base + col];
+        } else {
+            const int c = (col - 3) / (2 * L);
+            r = enc_value(v[base + c], (col - 3) - c * 2 * L);
+        }
+        *dst = r;
+    }
+}
+
+__host__ int grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 256 * 32 ? 256 * 32 : g));
+}
+
+}  // namespace
+
+extern "C" int nerf_amd_launch_gamma(const float* x, long long x_stride, float* out, long long n,
+                                     int L, hipStream_t stream) {
+    if (n == 0 || L == 0) return 0;
+    hipLaunchKernelGGL(gamma_kernel, dim3(grid_for(n * 2 * L)), dim3(256), 0, stream, x, x_stride, out, n, L);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nerf_amd_launch_posenc(const float* vec, float* posx, float* posd, long long P,
+                                      int Lp, int Ld, hipStream_t stream) {
+    if (P == 0) return 0;
+    hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(P * (6 + 6 * Lp + 6 * Ld))), dim3(256), 0, stream,
+                       vec, posx, posd, P, Lp, Ld);
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,279 @@
+// mlp_f32.hip -- fused sampling + positional encoding + 12-layer MLP for
+// gfx950 in EXACT fp32: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate; each
+// result is bit-for-bit an fmaf chain, cdna_hip_programming.md section 3).
+// The fp32 configuration of BASELINE.json (config 2) and the tight-tolerance
+// parity path against the CPU oracle.
+//
+// Same structure as mlp_bf16.hip (read its header first); differences:
+//   * 16-row output tiles, 16 points per wave, 8 waves = 128 points per tile;
+//   * an accumulator register is directly one k-step (4 features, one per lane
+//     group) of the next layer -- no conversion at all between layers;
+//   * the positional encoding uses the accurate ocml sinf/cosf on the exactly
+//     scaled argument, so inputs track the torch-CPU encoder to ~1 ulp.
+// Peak for this path is the fp32 MFMA rate, 157.3 TFLOP/s (1/16 of bf16).
+#include "nerf_device.h"
+#include <utility>
+
+using namespace nerf_layout;
+
+namespace {
+
+constexpr int WAVES = 8;
+constexpr int TILE_PTS = WAVES * 16;
+
+constexpr int LDS_WBUF = 24 * 1024;
+constexpr int LDS_BIAS = 0;
+constexpr int LDS_W0 = 10 * 1024;
+constexpr int LDS_POSD = LDS_W0 + 2 * LDS_WBUF;               // [wave][2][1 KiB]
+constexpr int LDS_POSX = LDS_POSD + WAVES * 2 * 1024;         // [wave][4][1 KiB]
+constexpr int LDS_TOTAL = LDS_POSX + WAVES * 4 * 1024;
+static_assert(F32_BIAS_FLOATS * 4 <= LDS_W0, "bias table");
+static_assert(F32_NUM_CHUNKS % 2 == 0, "buffer parity must repeat per tile");
+
+typedef __attribute__((address_space(3))) char lds_char;
+template <class T>
+__device__ __forceinline__ T lds_load(unsigned base, int imm) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) T*>(
+        reinterpret_cast<lds_char*>(0) + base + imm);
+}
+template <class T>
+__device__ __forceinline__ void lds_store(unsigned base, int imm, const T& v) {
+    *reinterpret_cast<__attribute__((address_space(3))) T*>(
+        reinterpret_cast<lds_char*>(0) + base + imm) = v;
+}
+
+__host__ __device__ constexpr int chunk_layer(int cc) {
+    int L = 0;
+    while (cc >= f32_mt(L)) { cc -= f32_mt(L); ++L; }
+    return L;
+}
+__host__ __device__ constexpr int chunk_first(int L) {
+    int c = 0;
+    for (int i = 0; i < L; ++i) c += f32_mt(i);
+    return c;
+}
+__host__ __device__ constexpr int chunk_off_kib(int cc) {
+    const int L = chunk_layer(cc);
+    return f32_layer_off_kib(L) + (cc - chunk_first(L)) * f32_chunk_kib(L);
+}
+__host__ __device__ constexpr int chunk_kib(int cc) { return f32_chunk_kib(chunk_layer(cc)); }
+
+struct Ctx {
+    __amdgpu_buffer_rsrc_t wrsrc;
+    unsigned wave_goff, lane16;
+    unsigned b_wread, b_wstore, b_bias, b_posx, b_posd;
+    int wave, lane;
+};
+
+template <int CC>
+struct Stage {
+    static constexpr int NEXT = (CC + 1) % F32_NUM_CHUNKS;
+    static constexpr int PIECES = (chunk_kib(NEXT) + WAVES - 1) / WAVES;
+    static constexpr int SRC_OFF = chunk_off_kib(NEXT) * 1024;
+    u32x4 r[PIECES];
+    __device__ __forceinline__ void load(const Ctx& c) {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p)
+            r[p] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                c.wrsrc, c.lane16, c.wave_goff + (SRC_OFF + p * WAVES * 1024), 0));
+    }
+    __device__ __forceinline__ void store(const Ctx& c) {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p)
+            lds_store<u32x4>(c.b_wstore, LDS_W0 + (NEXT & 1) * LDS_WBUF + p * (WAVES * 1024), r[p]);
+    }
+};
+
+// one chunk = 16-row output tile T of layer L
+template <int L, int T>
+__device__ __forceinline__ void chunk_step(const Ctx& c, const float (&in)[64], float (&out)[64],
+                                           float& sigma, float (&rgb)[3]) {
+    constexpr LayerDesc D = layer_desc(L);
+    constexpr int Q_CHAIN = D.chain_k / 16;         // groups of 4 k-steps from the chain
+    constexpr int Q_EXTRA = D.extra_slots / 16;
+    constexpr int Q = Q_CHAIN + Q_EXTRA;
+    constexpr int CC = chunk_first(L) + T;
+    constexpr int WB = LDS_W0 + (CC & 1) * LDS_WBUF;
+    constexpr int AHEAD = 2;
+    constexpr int BIAS_OFF = LDS_BIAS + (f32_bias_off(L) + 16 * T) * 4;
+
+    Stage<CC> st;
+    st.load(c);
+
+    // register i of lane group g is row 16T + 4g + i
+    f32x4 acc0 = lds_load<f32x4>(c.b_bias, BIAS_OFF);
+    f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 a[AHEAD];
+#pragma unroll
+    for (int q = 0; q < AHEAD && q < Q; ++q) a[q] = lds_load<f32x4>(c.b_wread, WB + q * 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const f32x4 aq = a[q % AHEAD];
+        if (q + AHEAD < Q) a[q % AHEAD] = lds_load<f32x4>(c.b_wread, WB + (q + AHEAD) * 1024);
+        f32x4 bq;
+        if (q < Q_CHAIN) {
+            const int qq = q < Q_CHAIN ? q : 0;
+            bq[0] = in[4 * qq + 0]; bq[1] = in[4 * qq + 1]; bq[2] = in[4 * qq + 2]; bq[3] = in[4 * qq + 3];
+        } else {
+            bq = lds_load<f32x4>(D.extra_kind == 1 ? c.b_posx : c.b_posd, (q - Q_CHAIN) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // two accumulation chains (dependent-issue latency 40 > issue 32 cycles)
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[0], bq[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[1], bq[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[2], bq[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[3], bq[3], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const f32x4 r = acc0 + acc1;
+    if constexpr (L == 10) {
+        rgb[0] = r[0]; rgb[1] = r[1]; rgb[2] = r[2];
+    } else if constexpr (L == 8 && T == 16) {
+        sigma = r[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) out[4 * T + i] = D.relu ? fmaxf(r[i], 0.f) : r[i];
+    }
+    st.store(c);
+    __syncthreads();
+}
+
+template <int L, int... Ts>
+__device__ __forceinline__ void run_layer_seq(const Ctx& c, const float (&in)[64], float (&out)[64],
+                                              float& sigma, float (&rgb)[3],
+                                              std::integer_sequence<int, Ts...>) {
+    (chunk_step<L, Ts>(c, in, out, sigma, rgb), ...);
+}
+template <int L>
+__device__ __forceinline__ void run_layer(const Ctx& c, const float (&in)[64], float (&out)[64],
+                                          float& sigma, float (&rgb)[3]) {
+    run_layer_seq<L>(c, in, out, sigma, rgb, std::make_integer_sequence<int, f32_mt(L)>{});
+}
+
+__device__ __forceinline__ float enc_exact(float x, int idx) {
+    const float a = ldexpf(x, idx >> 1);            // 2^level * x, exact
+    float s, co;
+    sincosf(a, &s, &co);
+    return (idx & 1) ? co : s;
+}
+
+template <bool RAYS>
+__device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base) {
+    const int col = c.lane & 15, g = c.lane >> 4;
+    long long p = tile_base + c.wave * 16 + col;
+    const bool valid = p < a.P;
+    if (!valid) p = a.P - 1;
+    PointIn pt;
+    if constexpr (RAYS) {
+        pt = fetch_point_rays(a, p);
+        if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
+    } else {
+        pt = fetch_point_pts(a, p);
+    }
+    // posx: 16 slots per lane group (nerf_layout::posx_col_f32)
+    {
+        const float xyz[3] = {pt.x, pt.y, pt.z};
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 15; ++t) v[t] = enc_exact(xyz[t / 5], 5 * g + t % 5);
+        v[15] = g == 0 ? pt.x : g == 1 ? pt.y : g == 2 ? pt.z : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 r = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            lds_store<f32x4>(c.b_posx, q * 1024, r);
+        }
+    }
+    // posd: 8 slots per lane group (nerf_layout::posd_col_f32)
+    {
+        const float dd[3] = {pt.d1, pt.d2, pt.d3};
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) v[t] = enc_exact(dd[t / 2], 2 * g + t % 2);
+        v[6] = g == 0 ? pt.d1 : g == 1 ? pt.d2 : g == 2 ? pt.d3 : 0.f;
+        v[7] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 r = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            lds_store<f32x4>(c.b_posd, q * 1024, r);
+        }
+    }
+}
+
+template <bool RAYS>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_f32_kernel(MlpArgs a, long long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)smem;
+    Ctx c;
+    c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.lane = threadIdx.x & 63;
+    c.wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.packed), 0,
+                                                (int)F32_PACKED_BYTES, 0x00020000);
+    c.wave_goff = c.wave * 1024;
+    c.lane16 = c.lane * 16;
+    c.b_wread = c.lane * 16;
+    c.b_wstore = c.wave * 1024 + c.lane * 16;
+    c.b_bias = (c.lane >> 4) * 16;
+    c.b_posx = LDS_POSX + c.wave * 4096 + c.lane * 16;
+    c.b_posd = LDS_POSD + c.wave * 2048 + c.lane * 16;
+
+    {
+        const float* bsrc = reinterpret_cast<const float*>(
+            reinterpret_cast<const char*>(a.packed) + (long long)F32_WEIGHT_KIB * 1024);
+        for (int i = threadIdx.x; i < F32_BIAS_FLOATS; i += WAVES * 64)
+            lds_store<float>(i * 4, LDS_BIAS, bsrc[i]);
+        Stage<F32_NUM_CHUNKS - 1> st;
+        st.load(c);
+        st.store(c);
+    }
+    __syncthreads();
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long tile_base = tile * TILE_PTS;
+        asm volatile("" : "+s"(c.wave_goff));
+        stage_inputs<RAYS>(c, a, tile_base);
+
+        float A[64], B[64];
+        float sigma, rgb[3];
+        run_layer<0>(c, A, A, sigma, rgb);
+        run_layer<1>(c, A, B, sigma, rgb);
+        run_layer<2>(c, B, A, sigma, rgb);
+        run_layer<3>(c, A, B, sigma, rgb);
+        run_layer<4>(c, B, A, sigma, rgb);
+        run_layer<5>(c, A, B, sigma, rgb);
+        run_layer<6>(c, B, A, sigma, rgb);
+        run_layer<7>(c, A, B, sigma, rgb);
+        run_layer<8>(c, B, A, sigma, rgb);
+        run_layer<9>(c, A, B, sigma, rgb);
+        run_layer<10>(c, B, A, sigma, rgb);
+
+        // rows 0..2 (rgb) / row 256 (sigma) are registers 0..2 / 0 of lane group 0
+        if (c.lane < 16) {
+            const long long p = tile_base + c.wave * 16 + c.lane;
+            if (p < a.P) {
+                const f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
+                *reinterpret_cast<f32x4*>(a.raw + p * 4) = o;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int nerf_amd_launch_mlp_f32(const MlpArgs* args, int rays_mode, hipStream_t stream) {
+    MlpArgs a = *args;
+    if (a.P <= 0) return 0;
+    const long long ntiles = (a.P + TILE_PTS - 1) / TILE_PTS;
+    int dev = 0, cus = 256;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return (int)e;
+    const long long grid = ntiles < cus ? ntiles : cus;
+    auto kern = rays_mode ? nerf_mlp_f32_kernel<true> : nerf_mlp_f32_kernel<false>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), LDS_TOTAL, stream, a, ntiles);
+    return (int)hipGetLastError();
+}

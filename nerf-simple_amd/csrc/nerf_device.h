@@ -1,0 +1,125 @@
+// nerf_device.h -- device helpers shared by the gfx950 kernels:
+// vector typedefs, the counter RNG, and per-point input assembly
+// (reference utils/rendering.py:24-40).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "nerf_layout.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+#define NERF_FLAG_TS_GIVEN 1u
+#define NERF_FLAG_DEVICE_RNG 2u
+
+// Arguments of the fused sampling + encoding + MLP kernels.
+struct MlpArgs {
+    const float* pts;     // points mode: [P,6]; rays mode: NULL
+    const float* rays;    // rays mode: [B,6]
+    const float* u;       // rays mode: jitter or ts [B,N] (NULL with DEVICE_RNG)
+    const float* tbins;   // rays mode: [N+1]
+    const void* packed;   // packed weight image
+    float* raw;           // out [P,4]
+    float* ts_out;        // rays mode: out [B,N] (may be NULL)
+    long long P;          // points = B*N
+    long long ray_id0;    // global id of ray 0 (device RNG counter base)
+    unsigned long long seed;
+    int N;
+    unsigned flags;
+};
+
+// ---- counter RNG: Philox-4x32-10 (Salmon et al. 2011), keyed by seed,
+// counter = global sample id.  One 32-bit word -> u in [0,1) with 24 bits, the
+// same granularity as torch.rand for float32.
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long ctr) {
+    unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0x6e657266u, c3 = 0x616d6421u;
+    unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+
+__device__ __forceinline__ float norm3(float x, float y, float z) {
+    return __fsqrt_rn(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+}
+
+// One query point: position (un-normalised direction times t) and the unit
+// direction, plus the sample position t (rays mode).
+struct PointIn {
+    float x, y, z, d1, d2, d3, t;
+};
+
+// rays mode (reference utils/rendering.py:24-40).  Every product/sum is
+// rounded separately (__fmul_rn/__fadd_rn: no fma contraction) exactly like
+// the reference's separate torch ops, so ts and locs are bit-identical to the
+// CPU path given the same u.
+__device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long p) {
+    PointIn r;
+    const long long b = p / a.N;
+    const int i = (int)(p - b * a.N);
+    const float* ray = a.rays + b * 6;
+    const float ox = ray[0], oy = ray[1], oz = ray[2];
+    const float dx = ray[3], dy = ray[4], dz = ray[5];
+    float t;
+    if (a.flags & NERF_FLAG_TS_GIVEN) {
+        t = a.u[p];
+    } else {
+        float u;
+        if (a.flags & NERF_FLAG_DEVICE_RNG)
+            u = philox_uniform(a.seed, (unsigned long long)((a.ray_id0 + b) * a.N + i));
+        else
+            u = a.u[p];
+        const float bin_diff = __fsub_rn(a.tbins[1], a.tbins[0]);
+        t = __fadd_rn(__fmul_rn(bin_diff, u), a.tbins[i]);
+    }
+    r.t = t;
+    r.x = __fadd_rn(ox, __fmul_rn(dx, t));
+    r.y = __fadd_rn(oy, __fmul_rn(dy, t));
+    r.z = __fadd_rn(oz, __fmul_rn(dz, t));
+    // torch.norm over 3 elements on CPU == sqrt(fma(z,z,fma(y,y,x*x))) bit for bit
+    const float nrm = norm3(dx, dy, dz);
+    r.d1 = __fdiv_rn(dx, nrm);
+    r.d2 = __fdiv_rn(dy, nrm);
+    r.d3 = __fdiv_rn(dz, nrm);
+    return r;
+}
+
+__device__ __forceinline__ PointIn fetch_point_pts(const MlpArgs& a, long long p) {
+    PointIn r;
+    const float* v = a.pts + p * 6;
+    r.x = v[0]; r.y = v[1]; r.z = v[2];
+    r.d1 = v[3]; r.d2 = v[4]; r.d3 = v[5];
+    r.t = 0.f;
+    return r;
+}
+
+// x / (2 pi) as an unevaluated sum hi + lo (|lo| <= ulp(hi)/2): scaling by 2^k
+// is exact and fract(hi * 2^k) is exact, so the phase of sin(2^k x) keeps
+// ~1e-7 rad accuracy even at |2^k x| ~ 2300 rad.
+struct TwoF { float hi, lo; };
+__device__ __forceinline__ TwoF to_revolutions(float x) {
+    const float C_HI = 0.15915494f;          // fl32(1/(2 pi))
+    const float C_LO = 6.4206382e-09f;       // 1/(2 pi) - C_HI
+    TwoF q;
+    q.hi = __fmul_rn(x, C_HI);
+    const float err = __fmaf_rn(x, C_HI, -q.hi);
+    q.lo = __fmaf_rn(x, C_LO, err);
+    return q;
+}
+// sin / cos of (2 pi * 2^k * q) via the hardware v_sin/v_cos (argument in
+// revolutions).  Accuracy ~1e-6 abs: used by the bf16 path only.
+__device__ __forceinline__ void sincos_rev_fast(TwoF q, float scale, float& s, float& c) {
+    const float f = __builtin_amdgcn_fractf(q.hi * scale) + q.lo * scale;
+    s = __builtin_amdgcn_sinf(f);
+    c = __builtin_amdgcn_cosf(f);
+}

@@ -1,0 +1,214 @@
+// nerf_layout.h -- index math shared by the weight packer, the fused MLP
+// kernels and the host-side layout self-test.  Plain C++ (no HIP types), all
+// functions constexpr so host and device compile the same formulas.
+//
+// The network (reference utils/nets.py:16-32) is re-expressed as 11 internal
+// layers whose OUTPUT features sit on MFMA rows and whose points sit on MFMA
+// columns (H^T = W . X^T), so that an accumulator tile of one layer is directly
+// the B operand of the next (cdna_hip_programming.md section 3, "An accumulator
+// tile as the next MFMA's operand"):
+//
+//   L0      posx(63->64 slots)            -> 256  relu   layers_0.0
+//   L1..L4  256                           -> 256  relu   layers_0.{2,4,6,8}
+//   L5      256 (h5) + posx 64 slots      -> 256  relu   skip_conn_layer.0  [h ; x]
+//   L6,L7   256                           -> 256  relu   layers_1.{0,2}
+//   L8      256 (h8)                      -> 288  none   rows 0..255 layers_2, row 256 sigma_fc, rest 0
+//   L9      256 (h9) + posd 32 slots      -> 128  relu   color_fc.0        [h ; d]
+//   L10     128                           -> 32   none   rows 0..2 color_fc.2, rest 0
+#pragma once
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define NL_HD __host__ __device__
+#else
+#define NL_HD
+#endif
+
+namespace nerf_layout {
+
+constexpr int NUM_LAYERS = 11;
+constexpr int PARAM_COUNT = 595844;
+
+// offsets of the 24 tensors inside the flat fp32 parameter vector
+// (PARAM_SPECS order of utils/synthetic.py == state_dict order of the reference)
+constexpr int OFF_L0_W = 0;                         // 256x63
+constexpr int OFF_L0_B = OFF_L0_W + 256 * 63;
+constexpr int OFF_L1_W = OFF_L0_B + 256;            // 4 x (256x256 + 256)
+constexpr int OFF_SKIP_W = OFF_L1_W + 4 * (256 * 256 + 256);   // 256x319
+constexpr int OFF_SKIP_B = OFF_SKIP_W + 256 * 319;
+constexpr int OFF_L6_W = OFF_SKIP_B + 256;          // 2 x (256x256 + 256)
+constexpr int OFF_SIG_W = OFF_L6_W + 2 * (256 * 256 + 256);    // 1x256
+constexpr int OFF_SIG_B = OFF_SIG_W + 256;
+constexpr int OFF_L2_W = OFF_SIG_B + 1;             // 256x256
+constexpr int OFF_L2_B = OFF_L2_W + 256 * 256;
+constexpr int OFF_C0_W = OFF_L2_B + 256;            // 128x283
+constexpr int OFF_C0_B = OFF_C0_W + 128 * 283;
+constexpr int OFF_C1_W = OFF_C0_B + 128;            // 3x128
+constexpr int OFF_C1_B = OFF_C1_W + 3 * 128;
+static_assert(OFF_C1_B + 3 == PARAM_COUNT, "parameter offsets");
+
+struct LayerDesc {
+    int w_off, b_off;     // into the flat parameter vector
+    int ld;               // row stride (= true K) of the source weight
+    int rows;             // true output rows held by the source weight
+    int chain_k;          // input features taken from the previous layer's accumulators
+    int extra_slots;      // posx (64) / posd (32) slots appended after the chain part
+    int extra_col0;       // first source column of the appended part
+    int extra_kind;       // 0 none, 1 posx, 2 posd
+    int mt;               // output tiles of 32 rows
+    int relu;
+};
+
+NL_HD constexpr LayerDesc layer_desc(int L) {
+    return L == 0 ? LayerDesc{OFF_L0_W, OFF_L0_B, 63, 256, 0, 64, 0, 1, 8, 1}
+         : L <= 4 ? LayerDesc{OFF_L1_W + (L - 1) * (256 * 256 + 256),
+                              OFF_L1_W + (L - 1) * (256 * 256 + 256) + 256 * 256,
+                              256, 256, 256, 0, 0, 0, 8, 1}
+         : L == 5 ? LayerDesc{OFF_SKIP_W, OFF_SKIP_B, 319, 256, 256, 64, 256, 1, 8, 1}
+         : L <= 7 ? LayerDesc{OFF_L6_W + (L - 6) * (256 * 256 + 256),
+                              OFF_L6_W + (L - 6) * (256 * 256 + 256) + 256 * 256,
+                              256, 256, 256, 0, 0, 0, 8, 1}
+         : L == 8 ? LayerDesc{OFF_L2_W, OFF_L2_B, 256, 256, 256, 0, 0, 0, 9, 0}
+         : L == 9 ? LayerDesc{OFF_C0_W, OFF_C0_B, 283, 128, 256, 32, 256, 2, 4, 1}
+         :          LayerDesc{OFF_C1_W, OFF_C1_B, 128, 3, 128, 0, 0, 0, 1, 0};
+}
+
+// padded K of a layer as the kernels see it
+NL_HD constexpr int layer_k(int L) { return layer_desc(L).chain_k + layer_desc(L).extra_slots; }
+
+// ---- k-permutations -------------------------------------------------------
+// bf16, mfma_f32_32x32x16_bf16: k-step s covers 16 k's; lane half h = lane>>5
+// holds elements j = 0..7.  An accumulator register r of a 32-row tile holds
+// row (r&3) + 8(r>>2) + 4h, so registers 8s..8s+7 converted to bf16 ARE the
+// fragment of k-step s with this feature order:
+NL_HD constexpr int chain_feat_bf16(int s, int h, int j) {
+    return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+}
+// f32, mfma_f32_16x16x4f32 (16-row tiles): k-step s covers 4 k's, one per lane
+// group g = lane>>4.  Accumulator register i of 16-row tile t holds row 4g + i,
+// so that register IS k-step 4t + i of the next layer:
+NL_HD constexpr int chain_feat_f32(int s, int g) {
+    return 16 * (s >> 2) + 4 * g + (s & 3);
+}
+
+// posx slots: each lane half evaluates 15 (coord, level) sin/cos pairs with a
+// STATIC coordinate and a level that is static + 5h, so the encoder needs no
+// per-lane selects.  slot t in [0,32) of half h -> source column of posx
+// (reference utils/xyz.py:33: [x,y,z, g(x)(20), g(y)(20), g(z)(20)], g = sin,cos
+// interleaved per level) or -1 for zero padding.
+NL_HD constexpr int posx_col(int t, int h) {
+    return t < 30 ? 3 + 20 * ((t >> 1) / 5) + 2 * (5 * h + (t >> 1) % 5) + (t & 1)
+         : t == 30 ? (h == 0 ? 0 : 2)
+         :           (h == 0 ? 1 : -1);
+}
+// posd slots t in [0,16) of half h (Ld = 4: 8 columns per coordinate)
+NL_HD constexpr int posd_col(int t, int h) {
+    return t < 12 ? 3 + 8 * ((t >> 1) / 2) + 2 * (2 * h + (t >> 1) % 2) + (t & 1)
+         : t == 12 ? (h == 0 ? 0 : 2)
+         : t == 13 ? (h == 0 ? 1 : -1)
+         :           -1;
+}
+
+// f32 slots (4 lane groups): group g evaluates, per coordinate, the five
+// (level, trig) pairs idx = 5g..5g+4 of the 20 (idx = 2*level + trig), and one
+// raw coordinate.  slot t in [0,16).
+NL_HD constexpr int posx_col_f32(int t, int g) {
+    return t < 15 ? 3 + 20 * (t / 5) + 5 * g + t % 5
+         :          (g < 3 ? g : -1);
+}
+// posd, slot t in [0,8): per coordinate the pair (level g, trig j)
+NL_HD constexpr int posd_col_f32(int t, int g) {
+    return t < 6 ? 3 + 8 * (t / 2) + 2 * g + t % 2
+         : t == 6 ? (g < 3 ? g : -1)
+         :          -1;
+}
+
+// source column of layer L's weight for MFMA k position, bf16 form:
+// ks = k-step (16 k's each) over [chain part | extra part]
+NL_HD constexpr int src_col_bf16(int L, int ks, int h, int j) {
+    const LayerDesc d = layer_desc(L);
+    const int chain_ks = d.chain_k / 16;
+    if (ks < chain_ks) return chain_feat_bf16(ks, h, j);
+    const int t = 8 * (ks - chain_ks) + j;
+    const int c = d.extra_kind == 1 ? posx_col(t, h) : posd_col(t, h);
+    return c < 0 ? -1 : d.extra_col0 + c;
+}
+// f32 form: ks = k-step (4 k's each), g = lane group
+NL_HD constexpr int src_col_f32(int L, int ks, int g) {
+    const LayerDesc d = layer_desc(L);
+    const int chain_ks = d.chain_k / 4;
+    if (ks < chain_ks) return chain_feat_f32(ks, g);
+    const int t = ks - chain_ks;
+    const int c = d.extra_kind == 1 ? posx_col_f32(t, g) : posd_col_f32(t, g);
+    return c < 0 ? -1 : d.extra_col0 + c;
+}
+
+// weight value W_L[row][col] (row < mt*32) out of the flat parameter vector,
+// 0 for padding; L8 row 256 is sigma_fc.
+template <class T>
+NL_HD inline float weight_at(const T* params, int L, int row, int col) {
+    if (col < 0) return 0.f;
+    const LayerDesc d = layer_desc(L);
+    if (L == 8 && row == 256) return params[OFF_SIG_W + col];
+    if (row >= d.rows) return 0.f;
+    return params[d.w_off + row * d.ld + col];
+}
+template <class T>
+NL_HD inline float bias_at(const T* params, int L, int row) {
+    const LayerDesc d = layer_desc(L);
+    if (L == 8 && row == 256) return params[OFF_SIG_B];
+    if (row >= d.rows) return 0.f;
+    return params[d.b_off + row];
+}
+
+// ---- packed bf16 image ----------------------------------------------------
+// chunk = (layer, 32-row output tile m): KS fragments of 1 KiB
+// (64 lanes x 8 bf16, lane-linear so that one ds_read_b128 / dwordx4 per lane
+// fetches a fragment), padded to a multiple of 4 KiB so the 4 waves of a
+// workgroup each move the same number of 1 KiB pieces.
+NL_HD constexpr int bf16_ks(int L) { return layer_k(L) / 16; }
+NL_HD constexpr int bf16_chunk_kib(int L) { return (bf16_ks(L) + 3) / 4 * 4; }
+NL_HD constexpr int bf16_layer_off_kib(int L) {
+    int o = 0;
+    for (int i = 0; i < L; ++i) o += layer_desc(i).mt * bf16_chunk_kib(i);
+    return o;
+}
+constexpr int BF16_WEIGHT_KIB = bf16_layer_off_kib(NUM_LAYERS);      // 1192
+NL_HD constexpr int bias_off(int L) {       // in floats, into the bias table
+    int o = 0;
+    for (int i = 0; i < L; ++i) o += layer_desc(i).mt * 32;
+    return o;
+}
+constexpr int BIAS_FLOATS = bias_off(NUM_LAYERS);                    // 2496
+constexpr long long BF16_PACKED_BYTES = (long long)BF16_WEIGHT_KIB * 1024 + BIAS_FLOATS * 4;
+constexpr int BF16_MAX_CHUNK_KIB = 20;
+constexpr int NUM_CHUNKS = 8 * 8 + 9 + 4 + 1;                        // 78
+
+// ---- packed f32 image -----------------------------------------------------
+// 16-row output tiles (mfma_f32_16x16x4f32).  chunk = (layer, t): K/4 k-steps
+// x 64 lanes x 4 B, stored [ks/4][lane][4] so one ds_read_b128 per lane covers
+// 4 consecutive k-steps.  A chunk is K*64 bytes -- the same size as the bf16
+// chunk of the same layer, so both kernels share the staging geometry.
+NL_HD constexpr int f32_mt(int L) { return L == 8 ? 17 : L == 10 ? 1 : layer_desc(L).mt * 2; }
+NL_HD constexpr int f32_ks(int L) { return layer_k(L) / 4; }
+NL_HD constexpr int f32_chunk_kib(int L) { return bf16_chunk_kib(L); }
+NL_HD constexpr int f32_layer_off_kib(int L) {
+    int o = 0;
+    for (int i = 0; i < L; ++i) o += f32_mt(i) * f32_chunk_kib(i);
+    return o;
+}
+constexpr int F32_WEIGHT_KIB = f32_layer_off_kib(NUM_LAYERS);
+NL_HD constexpr int f32_bias_off(int L) {
+    int o = 0;
+    for (int i = 0; i < L; ++i) o += f32_mt(i) * 16;
+    return o;
+}
+constexpr int F32_BIAS_FLOATS = f32_bias_off(NUM_LAYERS);
+constexpr long long F32_PACKED_BYTES = (long long)F32_WEIGHT_KIB * 1024 + F32_BIAS_FLOATS * 4;
+NL_HD constexpr int f32_num_chunks() {
+    int c = 0;
+    for (int i = 0; i < NUM_LAYERS; ++i) c += f32_mt(i);
+    return c;
+}
+constexpr int F32_NUM_CHUNKS = f32_num_chunks();                     // 154
+
+}  // namespace nerf_layout

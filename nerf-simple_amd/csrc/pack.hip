@@ -1,0 +1,83 @@
+// pack.hip -- fp32 state dict (flat, reference state_dict order) -> the
+// MFMA-fragment-ordered weight images streamed by the fused kernels.
+// Runs once per parameter update; one thread per packed element.
+#include "nerf_device.h"
+
+using namespace nerf_layout;
+
+namespace {
+
+// bf16 image: [chunk (layer, m)][k-step s][lane][8 bf16]; see nerf_layout.h
+__global__ void pack_bf16_kernel(const float* __restrict__ params, __bf16* __restrict__ out) {
+    const long long total = (long long)BF16_WEIGHT_KIB * 512;     // bf16 elements
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int kib = (int)(e >> 9);
+        int L = 0;
+        while (L + 1 < NUM_LAYERS && kib >= bf16_layer_off_kib(L + 1)) ++L;
+        const int rel = kib - bf16_layer_off_kib(L);
+        const int ck = bf16_chunk_kib(L);
+        const int m = rel / ck, s = rel % ck;
+        const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
+        float v = 0.f;
+        if (s < bf16_ks(L)) {
+            const int row = 32 * m + (lane & 31), h = lane >> 5;
+            v = weight_at(params, L, row, src_col_bf16(L, s, h, j));
+        }
+        out[e] = (__bf16)v;
+    }
+}
+
+// f32 image: [chunk (layer, t)][k-step/4][lane][4 f32]
+__global__ void pack_f32_kernel(const float* __restrict__ params, float* __restrict__ out) {
+    const long long total = (long long)F32_WEIGHT_KIB * 256;      // floats
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int kib = (int)(e >> 8);
+        int L = 0;
+        while (L + 1 < NUM_LAYERS && kib >= f32_layer_off_kib(L + 1)) ++L;
+        const int rel = kib - f32_layer_off_kib(L);
+        const int ck = f32_chunk_kib(L);
+        const int t = rel / ck, q = rel % ck;           // q: group of 4 k-steps (1 KiB)
+        const int lane = (int)(e >> 2) & 63, i = (int)e & 3;
+        const int ks = 4 * q + i;
+        float v = 0.f;
+        if (ks < f32_ks(L)) {
+            const int row = 16 * t + (lane & 15), g = lane >> 4;
+            v = weight_at(params, L, row, src_col_f32(L, ks, g));
+        }
+        out[e] = v;
+    }
+}
+
+// bias tables: natural row order, padded to whole tiles
+__global__ void pack_bias_kernel(const float* __restrict__ params, float* __restrict__ out, int f32_tiles) {
+    const int total = f32_tiles ? F32_BIAS_FLOATS : BIAS_FLOATS;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        int L = 0;
+        if (f32_tiles) {
+            while (L + 1 < NUM_LAYERS && e >= f32_bias_off(L + 1)) ++L;
+            out[e] = bias_at(params, L, e - f32_bias_off(L));
+        } else {
+            while (L + 1 < NUM_LAYERS && e >= bias_off(L + 1)) ++L;
+            out[e] = bias_at(params, L, e - bias_off(L));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int nerf_amd_launch_pack(const float* params, void* packed, int precision, hipStream_t stream) {
+    if (precision == 1) {
+        hipLaunchKernelGGL(pack_bf16_kernel, dim3(1024), dim3(256), 0, stream, params,
+                           reinterpret_cast<__bf16*>(packed));
+        float* bias = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + (long long)BF16_WEIGHT_KIB * 1024);
+        hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params, bias, 0);
+    } else {
+        hipLaunchKernelGGL(pack_f32_kernel, dim3(1024), dim3(256), 0, stream, params,
+                           reinterpret_cast<float*>(packed));
+        float* bias = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + (long long)F32_WEIGHT_KIB * 1024);
+        hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params, bias, 1);
+    }
+    return (int)hipGetLastError();
+}

@@ -1,0 +1,117 @@
+"""Drop-in for the reference's utils/nets.py: the ``Nerf`` module.
+
+Same constructor, same 24 state-dict keys and shapes (fp32 master weights,
+``load_state_dict(..., strict=True)`` compatible with reference checkpoints,
+reference utils/nets.py:9-32, test.py:28), but ``forward`` runs the fused HIP
+kernel (encoding + 12 dense layers in one launch, csrc/mlp_bf16.hip /
+csrc/mlp_f32.hip) on an MFMA-fragment-ordered copy of the weights.  That packed
+copy is a derived cache, rebuilt whenever a parameter changes.
+"""
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+DEFAULT_PRECISION = os.environ.get("NERF_AMD_PRECISION", "bf16")
+
+
+class Nerf(nn.Module):
+    """8x256 ReLU MLP with a skip-concat of the encoded position after layer 5,
+    a sigma head, and a view-direction colour head (reference utils/nets.py:8-43).
+
+    forward(v): v [P,6] = [x,y,z,d1,d2,d3] -> [P,4] = [r,g,b,sigma], raw (no
+    sigmoid on rgb; softplus on sigma is applied by the compositor).
+
+    precision: 'bf16' (bf16 MFMA operands, fp32 accumulate; default) or
+               'fp32' (exact-f32 MFMA).  Keyword-only superset of the
+               reference signature.
+    """
+
+    def __init__(self, Lp=10, Ld=4, H=256, *, precision=None):
+        super().__init__()
+        self.Lp, self.Ld, self.H = Lp, Ld, H
+        self.precision = precision or DEFAULT_PRECISION
+        _lib.precision_code(self.precision)
+        cx, cd = 3 + 6 * Lp, 3 + 6 * Ld
+
+        def relu_stack(dims):
+            mods = []
+            for a, b in zip(dims[:-1], dims[1:]):
+                mods += [nn.Linear(a, b), nn.ReLU()]
+            return nn.Sequential(*mods)
+
+        # module names fix the state-dict keys (checkpoint contract)
+        self.layers_0 = relu_stack([cx, H, H, H, H, H])
+        self.skip_conn_layer = relu_stack([H + cx, H])
+        self.layers_1 = relu_stack([H, H, H])
+        self.sigma_fc = nn.Sequential(nn.Linear(H, 1))
+        self.layers_2 = nn.Linear(H, H)
+        self.color_fc = nn.Sequential(nn.Linear(H + cd, H // 2), nn.ReLU(), nn.Linear(H // 2, 3))
+        self._packed = {}       # (device, precision code) -> (versions, packed uint8 tensor)
+
+    # ---- packed-weight cache ------------------------------------------------
+    def _fused_ok(self):
+        return (self.Lp, self.Ld, self.H) == (10, 4, 256)
+
+    def _param_list(self):
+        return [p for _, p in self.named_parameters()]
+
+    def packed_weights(self, precision=None):
+        """Device buffer with the weight image the fused kernels stream; packs on
+        first use and again after any in-place parameter update / reassignment."""
+        if not self._fused_ok():
+            raise RuntimeError("the fused HIP path is built for Nerf(Lp=10, Ld=4, H=256) only")
+        code = _lib.precision_code(precision or self.precision)
+        params = self._param_list()
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("Nerf must be moved to the GPU (.cuda()) before use; there is no CPU path")
+        key = (dev, code)
+        stamp = tuple((p.data_ptr(), p._version) for p in params)
+        hit = self._packed.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        lib = _lib.lib()
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+        if flat.numel() != lib.nerf_amd_param_count():
+            raise RuntimeError("unexpected parameter count")
+        packed = torch.empty(lib.nerf_amd_packed_bytes(code), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(flat), _lib.ptr(packed), code,
+                                                 _lib.stream_ptr(dev)), "nerf_amd_pack_weights")
+        self._packed[key] = (stamp, packed)
+        return packed
+
+    # ---- forward ---------------------------------------------------------------
+    def forward(self, v, *, precision=None):
+        _lib.require_cuda_f32(v, "v")
+        if v.dim() != 2 or v.shape[1] != 6:
+            raise RuntimeError("Nerf.forward expects a [P, 6] tensor")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from ..training import nerf_forward_autograd
+            return nerf_forward_autograd(self, v, precision or self.precision)
+        return self.forward_inference(v, precision=precision)
+
+    def forward_inference(self, v, *, precision=None):
+        code = _lib.precision_code(precision or self.precision)
+        packed = self.packed_weights(code)
+        v = v.detach().contiguous()
+        P = v.shape[0]
+        out = torch.empty((P, 4), dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(_lib.lib().nerf_amd_mlp_forward(_lib.ptr(v), _lib.ptr(packed), _lib.ptr(out),
+                                                       P, code, _lib.stream_ptr(v.device)),
+                       "nerf_amd_mlp_forward")
+        return out
+
+
+class CoarseNet(nn.Module):
+    """Placeholder, as in the reference (utils/nets.py:45-46: hierarchical
+    sampling is not implemented there)."""
+
+
+class FineNet(nn.Module):
+    """Placeholder, as in the reference (utils/nets.py:48-49)."""

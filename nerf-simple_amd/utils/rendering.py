@@ -1,0 +1,230 @@
+"""Drop-in for the hot path of the reference's utils/rendering.py.
+
+``render_nerf`` (alias ``render_rays``) and ``volume_render`` keep the
+reference's names, positional arguments, defaults and return order
+(reference utils/rendering.py:13,47); the bodies are HIP kernels behind
+libnerf_amd.so.  ``render_image`` / ``render_poses`` reproduce the batching and
+clipping semantics of the reference's image drivers (utils/rendering.py:88-153)
+without the video writer.
+
+Jitter: in parity mode (default) ``render_nerf`` draws exactly one
+``torch.rand(B, N)`` from the CPU default generator per call, as the reference
+does (utils/rendering.py:28), so a seeded run consumes the RNG identically.
+``u=`` / ``ts=`` inject explicit jitter / sample positions; ``device_rng=True``
+draws jitter from a counter RNG on the GPU instead (no PCIe copy, results
+independent of batching and sharding, not bit-comparable to the reference).
+"""
+import torch
+from tqdm import tqdm
+
+from .. import _lib
+from .nets import Nerf
+
+ALL_OUTPUTS = ("rgb", "disp", "alpha", "acc", "w")
+_tbins_cache = {}
+
+
+def _tbins(tn, tf, N, device):
+    key = (float(tn), float(tf), int(N), device)
+    t = _tbins_cache.get(key)
+    if t is None:
+        # computed on the host by torch.linspace so bin edges are bit-identical
+        # to the reference's (utils/rendering.py:25)
+        t = torch.linspace(tn, tf, N + 1).to(device)
+        if len(_tbins_cache) > 64:
+            _tbins_cache.clear()
+        _tbins_cache[key] = t
+    return t
+
+
+def _sample_positions(u, tn, tf):
+    """ts from jitter with torch ops on u's device (generic-net fallback only)."""
+    N = u.shape[1]
+    t_bins = torch.linspace(tn, tf, N + 1).to(u.device)
+    return (t_bins[1] - t_bins[0]) * u + t_bins[:-1]
+
+
+def volume_render(nerf_outs, ts, dirs, *, outputs=ALL_OUTPUTS):
+    """nerf_outs [B,N,4], ts [B,N], dirs [B,3] -> (rgb [B,3], disp [B], alpha [B,N],
+    acc [B], w [B,N])  (reference utils/rendering.py:47-85).  The second output is
+    disparity; acc == 0 yields NaN there, as in the reference."""
+    _lib.require_cuda_f32(nerf_outs, "nerf_outs")
+    _lib.require_cuda_f32(ts, "ts")
+    _lib.require_cuda_f32(dirs, "dirs")
+    if nerf_outs.dim() != 3 or nerf_outs.shape[-1] != 4:
+        raise RuntimeError("nerf_outs must be [B, N, 4]")
+    B, N = nerf_outs.shape[0], nerf_outs.shape[1]
+    if tuple(ts.shape) != (B, N) or tuple(dirs.shape) != (B, 3):
+        raise RuntimeError("ts must be [B, N] and dirs [B, 3]")
+    if torch.is_grad_enabled() and nerf_outs.requires_grad:
+        from ..training import volume_render_autograd
+        return volume_render_autograd(nerf_outs, ts, dirs)
+    dev = nerf_outs.device
+    raw, ts, dirs = nerf_outs.detach().contiguous(), ts.detach().contiguous(), dirs.detach().contiguous()
+    rgb = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((B,), dtype=torch.float32, device=dev)
+    acc = torch.empty((B,), dtype=torch.float32, device=dev)
+    alpha = torch.empty((B, N), dtype=torch.float32, device=dev) if "alpha" in outputs else None
+    w = torch.empty((B, N), dtype=torch.float32, device=dev) if "w" in outputs else None
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nerf_amd_volume_render(
+            _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(dirs), 3, _lib.ptr(rgb), _lib.ptr(disp),
+            _lib.ptr(alpha), _lib.ptr(acc), _lib.ptr(w), B, N, _lib.stream_ptr(dev)),
+            "nerf_amd_volume_render")
+    return rgb, disp, alpha, acc, w
+
+
+def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUTS,
+                precision=None, device_rng=False, seed=0, ray_id0=0, stage_events=None):
+    """Stratified sampling along rays, NeRF query, compositing
+    (reference utils/rendering.py:13-45).
+
+    rays [B,6] = [origin, direction] on the GPU; net: a ``Nerf`` (fused HIP path)
+    or any object with ``.forward(query_pts[P,6]) -> [P,4]`` (generic path: the
+    net runs as given, sampling and compositing still run here).
+    Returns (rgb [B,3], disp [B], alpha [B,N], acc [B], w [B,N]); alpha / w are
+    None when left out of ``outputs``.
+    stage_events: optional list; when given, the two kernels of the fused path
+    are launched through their own C entry points and a (start, end)
+    torch.cuda.Event pair bracketing the MLP kernel is appended (bench.py).
+    """
+    _lib.require_cuda_f32(rays, "rays")
+    if rays.dim() != 2 or rays.shape[1] != 6:
+        raise RuntimeError("rays must be [B, 6]")
+    B, N = rays.size(0), int(N)
+    dev = rays.device
+    rays = rays.detach().contiguous()
+
+    flags = 0
+    jit = None
+    if ts is not None:
+        jit, flags = _lib.require_cuda_f32(ts, "ts").contiguous(), _lib.FLAG_TS_GIVEN
+    elif u is not None:
+        jit = _lib.require_cuda_f32(u, "u").contiguous()
+    elif device_rng:
+        flags = _lib.FLAG_DEVICE_RNG
+    else:
+        jit = torch.rand(B, N).to(dev)        # the reference's single CPU draw per call (:28-30)
+    if jit is not None and tuple(jit.shape) != (B, N):
+        raise RuntimeError("u / ts must be [B, N]")
+
+    fused = isinstance(net, Nerf) and net._fused_ok()
+    training = fused and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
+    if training:
+        from ..training import render_nerf_autograd
+        return render_nerf_autograd(rays, net, N, tn, tf, jit, flags, precision or net.precision,
+                                    seed, ray_id0)
+    if not fused:
+        return _render_generic(rays, net, N, tn, tf, jit, flags, outputs, seed, ray_id0)
+
+    code = _lib.precision_code(precision or net.precision)
+    packed = net.packed_weights(code)
+    lib = _lib.lib()
+    rgb = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((B,), dtype=torch.float32, device=dev)
+    acc = torch.empty((B,), dtype=torch.float32, device=dev)
+    alpha = torch.empty((B, N), dtype=torch.float32, device=dev) if "alpha" in outputs else None
+    w = torch.empty((B, N), dtype=torch.float32, device=dev) if "w" in outputs else None
+    ws = torch.empty(max(int(lib.nerf_amd_render_workspace_bytes(B, N)), 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        st = _lib.stream_ptr(dev)
+        if stage_events is None:
+            _lib.check(lib.nerf_amd_render_forward(
+                _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)), _lib.ptr(packed), code,
+                flags, int(seed), int(ray_id0), _lib.ptr(rgb), _lib.ptr(disp), _lib.ptr(alpha),
+                _lib.ptr(acc), _lib.ptr(w), _lib.ptr(ws), B, N, st), "nerf_amd_render_forward")
+        else:
+            # the same two launches nerf_amd_render_forward makes, bracketed
+            raw = ws[:B * N * 16].view(torch.float32)
+            tsb = ws[(B * N * 16 + 255) // 256 * 256:][:B * N * 4].view(torch.float32)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.nerf_amd_mlp_forward_rays(
+                _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)), _lib.ptr(packed), code,
+                flags, int(seed), int(ray_id0), _lib.ptr(raw), _lib.ptr(tsb), B, N, st),
+                "nerf_amd_mlp_forward_rays")
+            e1.record()
+            stage_events.append((e0, e1))
+            dn = rays[:, 3:] / torch.norm(rays[:, 3:], dim=1, keepdim=True)
+            _lib.check(lib.nerf_amd_volume_render(
+                _lib.ptr(raw), _lib.ptr(tsb), _lib.ptr(dn.contiguous()), 3, _lib.ptr(rgb), _lib.ptr(disp),
+                _lib.ptr(alpha), _lib.ptr(acc), _lib.ptr(w), B, N, st), "nerf_amd_volume_render")
+    return rgb, disp, alpha, acc, w
+
+
+render_rays = render_nerf      # the name BASELINE.json uses for the same function
+
+
+def _render_generic(rays, net, N, tn, tf, jit, flags, outputs, seed, ray_id0):
+    """Any other net object: assemble query points with torch ops on the GPU
+    (utils/rendering.py:31-40), call net.forward as the reference does (:41),
+    composite with the HIP kernel."""
+    B = rays.size(0)
+    if flags & _lib.FLAG_TS_GIVEN:
+        ts = jit
+    else:
+        if flags & _lib.FLAG_DEVICE_RNG:
+            g = torch.Generator(device=rays.device).manual_seed(int(seed) + int(ray_id0))
+            jit = torch.rand(B, N, device=rays.device, generator=g)
+        ts = _sample_positions(jit, tn, tf)
+    o, d = rays[:, :3], rays[:, 3:]
+    locs = o.unsqueeze(-1) + d.unsqueeze(-1) * ts.unsqueeze(1)
+    dn = d / torch.norm(d, dim=1, keepdim=True)
+    q = torch.cat((locs, dn.unsqueeze(-1).expand(-1, -1, N)), dim=1).permute(0, 2, 1).reshape(-1, 6)
+    out = net.forward(q).reshape(B, N, 4)
+    return volume_render(out.float(), ts, dn, outputs=outputs)
+
+
+def _render_batched(rays, net, batch_size, N, tn, tf, u, progress, id_base=0, **kw):
+    """Shared body of the image drivers (reference utils/rendering.py:98-108,
+    139-151): per batch render_nerf under no_grad, clip rgb to [0,1] AFTER
+    compositing, disparity un-clipped.  Unlike the reference's
+    ``range(n // batch_size)`` the tail batch is rendered too."""
+    n = rays.size(0)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=rays.device)
+    disp = torch.empty((n,), dtype=torch.float32, device=rays.device)
+    starts = range(0, n, batch_size)
+    with torch.no_grad():
+        for s in (tqdm(starts) if progress else starts):
+            e = min(s + batch_size, n)
+            r, d, _, _, _ = render_nerf(rays[s:e], net, N, tn, tf,
+                                        u=None if u is None else u[s:e],
+                                        outputs=("rgb", "disp", "acc"), ray_id0=id_base + s, **kw)
+            rgb[s:e] = torch.clip(r, 0., 1.)
+            disp[s:e] = d
+    return rgb, disp
+
+
+def render_image(net, rg, batch_size=64000, im_idx=0, im_set='val', *, N=128, tn=2, tf=6,
+                 u=None, progress=False, **kw):
+    """Render image ``im_idx`` of ``rg``'s ``im_set`` (reference utils/rendering.py:88-113).
+    ``rg`` is any object with the reference RayGenerator's fields
+    ``samples[im_set][i]['img']`` and ``rays_dataset[im_set]`` ([n_img*H*W, 6]).
+    Returns (rgb [1,H,W,3], disparity [1,H,W,1], gt [1,H,W,3]) on the CPU."""
+    gt = rg.samples[im_set][im_idx]['img']
+    H, W = gt.shape[0], gt.shape[1]
+    dev = next(net.parameters()).device
+    rays = rg.rays_dataset[im_set][im_idx * H * W:(im_idx + 1) * H * W, :].to(dev).float()
+    rgb, disp = _render_batched(rays, net, batch_size, N, tn, tf, u, progress, **kw)
+    return rgb.cpu().reshape(1, H, W, 3), disp.cpu().reshape(1, H, W, 1), gt.reshape(1, H, W, 3)
+
+
+def render_poses(net, poses, cam_params, batch_size, savepath='', *, N=128, tn=2, tf=6,
+                 u=None, progress=False, **kw):
+    """Render one image per pose (reference utils/rendering.py:116-153).
+    poses: list of [4,4] float tensors; cam_params [H,W,f].  Returns
+    (rgb_imgs, disp_imgs): lists of numpy [H,W,3] / [H,W].  The reference's mp4
+    writer (cv2, :155-160) is out of scope; ``savepath`` is accepted and ignored."""
+    from .xyz import camera_rays
+    H, W = cam_params[0], cam_params[1]
+    dev = next(net.parameters()).device
+    rays_all = camera_rays(poses, cam_params).to(dev)
+    rgb_imgs, disp_imgs = [], []
+    for i in range(len(poses)):
+        rays = rays_all[i * H * W:(i + 1) * H * W]
+        ui = None if u is None else u[i * H * W:(i + 1) * H * W]
+        rgb, disp = _render_batched(rays, net, batch_size, N, tn, tf, ui, progress,
+                                    id_base=i * H * W, **kw)
+        rgb_imgs.append(rgb.cpu().reshape(H, W, 3).numpy())
+        disp_imgs.append(disp.cpu().reshape(H, W).numpy())
+    return rgb_imgs, disp_imgs

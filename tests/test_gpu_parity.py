@@ -1,0 +1,344 @@
+"""GPU parity tests: the HIP path (through the C ABI, via the Python host
+mirror) against the golden vectors captured from the reference and against
+the CPU oracle on seeded inputs.
+
+Tolerances (stated once, used below):
+  ENC_ATOL   encoder vs torch-CPU: ocml sinf/cosf on the exactly scaled
+             argument, ~1-2 ulp of a value in [-1,1].
+  F32_*      exact-f32 MFMA path vs CPU fp32: same arithmetic, different
+             summation order (k-permuted fma chain vs MKL sgemm blocking) through
+             12 layers; observed ~1e-6 relative, bound 1e-4 of the output scale.
+  BF16_*     bf16 operands (8-bit mantissa) with fp32 accumulation: ~3e-3
+             relative per layer, bound 4e-2 of the output scale; the image-level
+             criterion is PSNR (test_image_psnr).
+  CMP_RTOL   compositor alone: identical formulas, scan order differs from
+             torch.cumprod's sequential order by a few ulp.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ENC_ATOL = 5e-7
+F32_TOL = 1e-4
+BF16_TOL = 4e-2
+CMP_RTOL = 2e-5
+CMP_ATOL = 1e-6
+NAMES = ("rgb", "disp", "alpha", "acc", "w")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "run with a GPU: pytest -m gpu"
+    from nerf_simple_amd import _lib
+    _lib.lib()            # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def make_net(synthetic, dev, kind, precision="fp32"):
+    from nerf_simple_amd.utils.nets import Nerf
+    net = Nerf(precision=precision).to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, kind), strict=True)
+    return net
+
+
+def scaled_err(got, want):
+    want = np.asarray(want, dtype=np.float64)
+    got = np.asarray(got, dtype=np.float64)
+    scale = max(1.0, float(np.nanmax(np.abs(want))))
+    return float(np.nanmax(np.abs(got - want))) / scale
+
+
+# ---------------------------------------------------------------- encoding
+def test_encode_golden(dev, golden):
+    from nerf_simple_amd.utils.xyz import positional_encoder, gamma
+    g = golden("encode.npz")
+    v = t(g["v"]).to(dev)
+    posx, posd = positional_encoder(v)
+    assert posx.shape == (256, 63) and posd.shape == (256, 27)
+    assert np.abs(posx.cpu().numpy() - g["posx"]).max() <= ENC_ATOL
+    assert np.abs(posd.cpu().numpy() - g["posd"]).max() <= ENC_ATOL
+    # raw coordinates are copied exactly
+    assert np.array_equal(posx.cpu().numpy()[:, :3], g["v"][:, :3])
+    g7 = gamma(v[:, 0:1], L=7)         # a strided column view, non-default L
+    assert np.abs(g7.cpu().numpy() - g["gamma7_x"]).max() <= ENC_ATOL
+    # multi-column gamma follows the reference's cat layout
+    g2 = gamma(v[:, 0:2], L=3).cpu()
+    a, b = gamma(v[:, 0:1], L=3).cpu(), gamma(v[:, 1:2], L=3).cpu()
+    want = torch.stack([a, b], dim=2).reshape(256, 12)
+    assert torch.equal(g2, want)
+
+
+def test_encode_empty_and_other_levels(dev, oracle):
+    from nerf_simple_amd.utils.xyz import positional_encoder
+    v = torch.zeros(0, 6, device=dev)
+    px, pd = positional_encoder(v)
+    assert px.shape == (0, 63) and pd.shape == (0, 27)
+    v = torch.randn(33, 6, generator=torch.Generator().manual_seed(5))
+    px, pd = positional_encoder(v.to(dev), Lp=6, Ld=2)
+    wx, wd = oracle.positional_encoder(v, Lp=6, Ld=2)
+    assert (px.cpu() - wx).abs().max() <= ENC_ATOL and (pd.cpu() - wd).abs().max() <= ENC_ATOL
+
+
+# ---------------------------------------------------------------- the MLP
+@pytest.mark.parametrize("kind", ["default", "structured"])
+@pytest.mark.parametrize("precision,tol", [("fp32", F32_TOL), ("bf16", BF16_TOL)])
+def test_mlp_golden(dev, golden, synthetic, kind, precision, tol):
+    g = golden(f"mlp_{kind}.npz")
+    net = make_net(synthetic, dev, kind, precision)
+    with torch.no_grad():
+        out = net.forward(t(g["v"]).to(dev))
+    assert out.shape == (512, 4)
+    err_rgb = scaled_err(out.cpu().numpy()[:, :3], g["out"][:, :3])
+    err_sig = scaled_err(out.cpu().numpy()[:, 3], g["out"][:, 3])
+    print(f"mlp {kind} {precision}: rgb {err_rgb:.3e} sigma {err_sig:.3e}")
+    assert err_rgb <= tol and err_sig <= tol
+
+
+@pytest.mark.parametrize("P", [1, 31, 257, 1000])
+def test_mlp_ragged_sizes(dev, oracle, synthetic, P):
+    """Tiles are 128 (fp32) / 256 (bf16) points: partial tiles must be masked."""
+    sd = synthetic.synthetic_state_dict(0, "structured")
+    v = synthetic.points_in_scene(P, seed=P)
+    with torch.no_grad():
+        want = oracle.nerf_forward(sd, v).numpy()
+    for precision, tol in (("fp32", F32_TOL), ("bf16", BF16_TOL)):
+        net = make_net(synthetic, dev, "structured", precision)
+        guard = torch.full((P + 64, 4), 777.0, device=dev)
+        with torch.no_grad():
+            out = net.forward(v.to(dev))
+        assert scaled_err(out.cpu().numpy(), want) <= tol
+        del guard
+    with torch.no_grad():
+        assert make_net(synthetic, dev, "default").forward(torch.zeros(0, 6, device=dev)).shape == (0, 4)
+
+
+def test_mlp_repack_after_update(dev, oracle, synthetic):
+    """The packed image is a derived cache: it must follow parameter updates."""
+    net = make_net(synthetic, dev, "default", "fp32")
+    v = synthetic.points_in_scene(64, seed=3)
+    with torch.no_grad():
+        a = net.forward(v.to(dev)).cpu()
+        net.sigma_fc[0].bias.add_(1.0)
+        b = net.forward(v.to(dev)).cpu()
+    assert torch.allclose(b[:, 3], a[:, 3] + 1.0, atol=1e-5)
+    sd2 = synthetic.synthetic_state_dict(5, "default")
+    net.load_state_dict(sd2)
+    with torch.no_grad():
+        c = net.forward(v.to(dev)).cpu()
+        want = oracle.nerf_forward(sd2, v)
+    assert scaled_err(c.numpy(), want.numpy()) <= F32_TOL
+
+
+# ---------------------------------------------------------------- compositing
+def _check_composite(outs, g, pre):
+    for n, o in zip(NAMES, outs):
+        want = g[f"{pre}_{n}"]
+        got = o.cpu().numpy()
+        assert got.shape == want.shape, (pre, n)
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (pre, n, "NaN pattern")
+        np.testing.assert_allclose(got, want, rtol=CMP_RTOL, atol=CMP_ATOL, equal_nan=True,
+                                   err_msg=f"{pre}_{n}")
+
+
+def test_composite_golden(dev, golden):
+    from nerf_simple_amd.utils.rendering import volume_render
+    g = golden("composite.npz")
+    d1 = t(g["kat_dirs"]).to(dev)
+    _check_composite(volume_render(t(g["kat_raw"]).to(dev), t(g["kat_ts"]).to(dev), d1), g, "kat")
+    # sigma = -200 everywhere: acc = 0 -> rgb 0, disparity NaN (reference semantics)
+    outs = volume_render(t(g["nan_raw"]).to(dev), t(g["kat_ts"]).to(dev), d1)
+    assert torch.isnan(outs[1]).all() and (outs[0] == 0).all()
+    _check_composite(outs, g, "nan")
+    _check_composite(volume_render(t(g["sp_raw"]).to(dev), t(g["sp_ts"]).to(dev), d1), g, "sp")
+    for N in (32, 64, 128, 192):
+        outs = volume_render(t(g[f"rnd{N}_raw"]).to(dev), t(g[f"rnd{N}_ts"]).to(dev),
+                             t(g[f"rnd{N}_dirs"]).to(dev))
+        _check_composite(outs, g, f"rnd{N}")
+
+
+def test_composite_odd_sizes(dev, oracle):
+    from nerf_simple_amd.utils.rendering import volume_render
+    gen = torch.Generator().manual_seed(9)
+    for B, N in ((1, 1), (3, 2), (5, 65), (2, 300)):
+        raw = torch.randn(B, N, 4, generator=gen)
+        ts = torch.sort(torch.rand(B, N, generator=gen) * 4 + 2, dim=1).values
+        d = torch.randn(B, 3, generator=gen)
+        want = oracle.volume_render(raw, ts, d)
+        outs = volume_render(raw.to(dev), ts.to(dev), d.to(dev))
+        for n, o, r in zip(NAMES, outs, want):
+            np.testing.assert_allclose(o.cpu().numpy(), r.numpy(), rtol=CMP_RTOL, atol=CMP_ATOL, err_msg=n)
+    outs = volume_render(torch.zeros(4, 8, 4, device=dev), torch.zeros(4, 8, device=dev) + 2,
+                         torch.ones(4, 3, device=dev), outputs=("rgb", "disp", "acc"))
+    assert outs[2] is None and outs[4] is None
+
+
+# ---------------------------------------------------------------- render_nerf
+@pytest.mark.parametrize("kind", ["default", "structured"])
+@pytest.mark.parametrize("precision,tol", [("fp32", F32_TOL), ("bf16", BF16_TOL)])
+def test_render_golden(dev, golden, synthetic, kind, precision, tol):
+    from nerf_simple_amd.utils.rendering import render_nerf, render_rays
+    assert render_rays is render_nerf
+    g = golden(f"render_{kind}.npz")
+    net = make_net(synthetic, dev, kind, precision)
+    rays = t(g["rays"]).to(dev)
+    for N in (32, 64, 128, 192):
+        with torch.no_grad():
+            outs = render_nerf(rays, net, N, u=t(g[f"N{N}_u"]).to(dev))
+        errs = {}
+        for n, o in zip(NAMES, outs):
+            errs[n] = scaled_err(o.cpu().numpy(), g[f"N{N}_{n}"])
+        print(f"render {kind} {precision} N={N}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
+        assert max(errs.values()) <= tol, errs
+
+
+def test_render_rng_consumption(dev, golden, synthetic):
+    """Default mode draws ONE torch.rand(B,N) from the CPU generator per call,
+    like the reference (utils/rendering.py:28): seeding reproduces the golden."""
+    from nerf_simple_amd.utils.rendering import render_nerf
+    g = golden("render_structured.npz")
+    net = make_net(synthetic, dev, "structured", "fp32")
+    rays = t(g["rays"]).to(dev)
+    torch.manual_seed(int(g["N64_seed"]))
+    with torch.no_grad():
+        a = render_nerf(rays, net, 64)
+    after = torch.rand(1)
+    with torch.no_grad():
+        b = render_nerf(rays, net, 64, u=t(g["N64_u"]).to(dev))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    torch.manual_seed(int(g["N64_seed"]))
+    torch.rand(256, 64)
+    assert torch.equal(after, torch.rand(1))
+    assert scaled_err(a[0].cpu().numpy(), g["N64_rgb"]) <= F32_TOL
+
+
+def test_render_ts_given_and_sample_positions(dev, golden, synthetic, oracle):
+    """Explicit ts (needed by an importance-sampling caller) and bit-exact
+    sample positions from u: ts = bin_diff*u + t_bins[:-1] rounded as torch does."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.rendering import render_nerf
+    g = golden("render_structured.npz")
+    net = make_net(synthetic, dev, "structured", "fp32")
+    rays = t(g["rays"]).to(dev)
+    u = t(g["N128_u"])
+    ts = oracle.sample_ts(u)
+    with torch.no_grad():
+        a = render_nerf(rays, net, 128, u=u.to(dev))
+        b = render_nerf(rays, net, 128, ts=ts.to(dev))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), "ts computed in-kernel must equal torch's ts bit for bit"
+
+
+def test_render_generic_net(dev, golden, synthetic):
+    """Any object with .forward(query_pts) works as ``net`` (utils/rendering.py:41)."""
+    from nerf_simple_amd.utils.rendering import render_nerf
+    g = golden("render_structured.npz")
+    net = make_net(synthetic, dev, "structured", "fp32")
+
+    class Wrapped:
+        def forward(self, q):
+            return net.forward_inference(q)
+
+    u = t(g["N64_u"]).to(dev)
+    with torch.no_grad():
+        a = render_nerf(t(g["rays"]).to(dev), Wrapped(), 64, u=u)
+    for n, o in zip(NAMES, a):
+        assert scaled_err(o.cpu().numpy(), g[f"N64_{n}"]) <= F32_TOL, n
+
+
+def test_device_rng(dev, synthetic):
+    """Counter RNG: uniform in [0,1), reproducible, independent of batching."""
+    from nerf_simple_amd.utils.rendering import render_nerf
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    net = make_net(synthetic, dev, "structured", "bf16")
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 10)).float()
+    rays = camera_rays([pose], [40, 40, synthetic.focal_from_fov(40)]).to(dev)
+    with torch.no_grad():
+        full = render_nerf(rays, net, 64, device_rng=True, seed=7)
+        parts = [render_nerf(rays[s:s + 400], net, 64, device_rng=True, seed=7, ray_id0=s)
+                 for s in range(0, 1600, 400)]
+        other = render_nerf(rays, net, 64, device_rng=True, seed=8)
+    for i in range(5):
+        assert torch.equal(full[i], torch.cat([p[i] for p in parts])), NAMES[i]
+    assert not torch.equal(full[0], other[0])
+    # recover the jitter through the sample positions: t = tn + (i + u) * (tf-tn)/N
+    from nerf_simple_amd import _lib
+    lib = _lib.lib()
+    B, N = 512, 64
+    raw = torch.empty(B, N, 4, device=dev)
+    ts = torch.empty(B, N, device=dev)
+    tb = torch.linspace(2, 6, N + 1).to(dev)
+    _lib.check(lib.nerf_amd_mlp_forward_rays(_lib.ptr(rays[:B].contiguous()), None, _lib.ptr(tb),
+                                             _lib.ptr(net.packed_weights()), 1, 2, 7, 0,
+                                             _lib.ptr(raw), _lib.ptr(ts), B, N, _lib.stream_ptr(dev)), "x")
+    u = ((ts.cpu() - tb.cpu()[:-1]) / (4.0 / N)).numpy()
+    assert u.min() >= -1e-4 and u.max() < 1 + 1e-4
+    assert abs(u.mean() - 0.5) < 0.01 and abs(u.var() - 1 / 12) < 0.01
+    assert abs(np.corrcoef(u[:, :-1].ravel(), u[:, 1:].ravel())[0, 1]) < 0.02
+
+
+# ---------------------------------------------------------------- images
+@pytest.mark.parametrize("kind", ["default", "structured"])
+def test_image_golden_fp32(dev, golden, synthetic, kind):
+    """Config 1 (100x100, N=32) through the image driver: pixel order, clip after
+    compositing, disparity un-clipped, independence of batch size."""
+    from nerf_simple_amd.utils.rendering import render_poses
+    g = golden(f"image_{kind}.npz")
+    u = t(golden("image_u.npz")["u"]).to(dev)
+    net = make_net(synthetic, dev, kind, "fp32")
+    f = synthetic.focal_from_fov(100)
+    pose = t(g["pose"])
+    rgbs, disps = render_poses(net, [pose], [100, 100, f], batch_size=int(g["batch_size"]), N=32, u=u)
+    rgb, disp = rgbs[0].reshape(-1, 3), disps[0].reshape(-1)
+    assert scaled_err(rgb, g["rgb"]) <= F32_TOL and scaled_err(disp, g["disp"]) <= F32_TOL
+    assert rgb.min() >= 0.0 and rgb.max() <= 1.0
+    # a non-divisor batch size renders the tail too and changes nothing
+    rgbs2, disps2 = render_poses(net, [pose], [100, 100, f], batch_size=3333, N=32, u=u)
+    assert np.array_equal(rgbs2[0], rgbs[0]) and np.array_equal(disps2[0], disps[0])
+
+
+def test_image_psnr_bf16(dev, golden, synthetic, oracle):
+    """BASELINE criterion: |PSNR(GPU,T) - PSNR(CPU,T)| <= 0.05 dB against a
+    synthetic target T (CPU render of a perturbed 'teacher'), reference PSNR
+    formula (train.py:21-26); plus PSNR(GPU, CPU) itself."""
+    from nerf_simple_amd.utils.rendering import render_poses
+    g = golden("image_structured.npz")
+    u_cpu = t(golden("image_u.npz")["u"])
+    net = make_net(synthetic, dev, "structured", "bf16")
+    f = synthetic.focal_from_fov(100)
+    rgbs, _ = render_poses(net, [t(g["pose"])], [100, 100, f], batch_size=2500, N=32, u=u_cpu.to(dev))
+    gpu = torch.from_numpy(rgbs[0].reshape(-1, 3))
+    cpu = t(g["rgb"])
+    teacher = synthetic.perturbed_state_dict(synthetic.synthetic_state_dict(0, "structured"), seed=1, rel=0.02)
+    rays = oracle.camera_rays(t(g["pose"]), [100, 100, f])
+    T, _ = oracle.render_image(teacher, rays, 2500, N=32, u=u_cpu)
+    p_gpu, p_cpu = float(oracle.img_psnr(T, gpu)), float(oracle.img_psnr(T, cpu))
+    p_gc = float(oracle.img_psnr(cpu, gpu))
+    print(f"PSNR(CPU,T)={p_cpu:.3f} dB PSNR(GPU,T)={p_gpu:.3f} dB PSNR(GPU,CPU)={p_gc:.2f} dB")
+    assert abs(p_gpu - p_cpu) <= 0.05
+    assert p_gc >= 35.0
+
+
+def test_large_batch_properties(dev, synthetic):
+    """BASELINE-size batch (16000 rays x 128 samples, the reference's test batch):
+    size-independent properties instead of a CPU comparison -- weights sum to acc,
+    alpha in [0,1], acc <= 1, w = alpha * exclusive product."""
+    from nerf_simple_amd.utils.rendering import render_nerf
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    net = make_net(synthetic, dev, "structured", "bf16")
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
+    rays = camera_rays([pose], [800, 800, synthetic.focal_from_fov(800)])[320000:336000].to(dev)
+    with torch.no_grad():
+        rgb, disp, alpha, acc, w = render_nerf(rays, net, 128, device_rng=True, seed=1)
+    assert torch.isfinite(rgb).all() and torch.isfinite(disp).all()
+    assert (alpha >= 0).all() and (alpha <= 1).all()
+    assert torch.allclose(w.sum(1), acc, rtol=1e-5, atol=1e-6)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], 1), 1)[:, :-1]
+    assert torch.allclose(w, alpha * T, rtol=1e-4, atol=1e-7)
+    assert (acc <= 1 + 1e-5).all() and (acc > 0).all()

@@ -1,0 +1,112 @@
+"""CPU-side checks of the C-ABI library: it loads without a GPU, exports every
+symbol include/nerf_amd.h declares, and its host-side layout math is sane.
+No compute entry point is called here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nerf_amd.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from nerf_simple_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.lib()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nerf_amd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    from nerf_simple_amd import _lib
+    syms = declared_symbols()
+    assert len(syms) >= 13
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/nerf_amd.h but not exported"
+    # the Python binding covers exactly the header
+    assert sorted(_lib.EXPORTS) == syms
+
+
+def test_introspection(lib):
+    assert lib.nerf_amd_abi_version() == 1
+    assert lib.nerf_amd_param_count() == 595844
+    assert lib.nerf_amd_packed_bytes(1) == 1192 * 1024 + 2496 * 4
+    assert lib.nerf_amd_packed_bytes(0) == 2360 * 1024 + 154 * 16 * 4
+    assert lib.nerf_amd_packed_bytes(7) < 0
+    assert lib.nerf_amd_render_workspace_bytes(16000, 128) >= 16000 * 128 * 20
+    assert lib.nerf_amd_render_workspace_bytes(-1, 128) < 0
+
+
+def test_layout_selfcheck(lib):
+    assert lib.nerf_amd_layout_selfcheck() == 0
+
+
+def test_layout_maps(lib):
+    """Spot-check the k-permutations against their definitions (csrc/nerf_layout.h)."""
+    # bf16 chain order: element j of lane half h in k-step s is feature
+    # 16s + 8(j>>2) + 4h + (j&3)  (accumulator row order of mfma 32x32x16)
+    for s in range(16):
+        for h in range(2):
+            for j in range(8):
+                assert lib.nerf_amd_layout_src_col(1, 1, s, h, j) == 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)
+    # skip layer: chain part then posx slots offset by 256 ([h ; x], h first)
+    cols = sorted(lib.nerf_amd_layout_src_col(1, 5, s, h, j)
+                  for s in range(16, 20) for h in range(2) for j in range(8))
+    assert cols == [-1] + list(range(256, 319))
+    # layer 0 covers the 63 posx columns exactly once
+    cols = sorted(lib.nerf_amd_layout_src_col(1, 0, s, h, j)
+                  for s in range(4) for h in range(2) for j in range(8))
+    assert cols == [-1] + list(range(63))
+    # f32 chain order: register i of tile t in lane group g is feature 16t + 4g + i
+    for s in range(64):
+        for g in range(4):
+            assert lib.nerf_amd_layout_src_col(0, 2, s, g, 0) == 16 * (s >> 2) + 4 * g + (s & 3)
+    cols = sorted(lib.nerf_amd_layout_src_col(0, 9, s, g, 0) for s in range(64, 72) for g in range(4))
+    assert cols == [-1] * 5 + list(range(256, 283))
+
+
+def test_no_cpu_fallback():
+    """The product path refuses CPU tensors instead of computing on the host."""
+    import torch
+    from nerf_simple_amd.utils import rendering, xyz, nets
+    with pytest.raises(RuntimeError):
+        xyz.positional_encoder(torch.zeros(4, 6))
+    with pytest.raises(RuntimeError):
+        rendering.volume_render(torch.zeros(2, 4, 4), torch.zeros(2, 4), torch.zeros(2, 3))
+    with pytest.raises(RuntimeError):
+        rendering.render_nerf(torch.zeros(2, 6), nets.Nerf(), 8)
+    with pytest.raises(AssertionError):
+        xyz.gamma([1.0, 2.0])
+
+
+def test_state_dict_contract(synthetic):
+    """24 keys / shapes of the reference checkpoint format."""
+    from nerf_simple_amd.utils.nets import Nerf
+    net = Nerf()
+    sd = net.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, s) for k, s in synthetic.PARAM_SPECS]
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "structured"), strict=True)
+    assert sum(p.numel() for p in net.parameters()) == 595844
+
+
+def test_host_camera_helpers(golden):
+    import torch
+    import numpy as np
+    from nerf_simple_amd.utils import xyz
+    g = golden("camera.npz")
+    assert np.array_equal(xyz.rays_single_cam([100, 100, float(g["f"])]).numpy(), g["dirs100"])
+    assert np.array_equal(xyz.rays_single_cam([6, 10, 7.5]).numpy(), g["dirs_6x10"])
+    assert np.array_equal(xyz.spherical_to_pose(4, -30, 40), g["pose_4_m30_40"])
+    assert np.array_equal(torch.stack(xyz.poses_to_render(4, -30, 5)).numpy(), g["poses5"])
+    pose = torch.from_numpy(xyz.spherical_to_pose(4, -30, 40)).float()
+    assert np.array_equal(xyz.camera_rays([pose], [100, 100, float(g["f"])]).numpy(), g["rays100_phi40"])
