@@ -48,11 +48,28 @@ def parse():
     return ap.parse_args()
 
 
+def host_cores():
+    """CPU threads this process may actually use: affinity mask, then the cgroup
+    CPU quota (a GPU box hands each job a share of a much larger host)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, int(os.environ.get("NERF_BENCH_CPU_THREADS", "32")))
+
+
 def cpu_baseline(sd, rays_cpu, n_rays):
     """Time the CPU oracle on one n_rays x 128 batch of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import nerf_oracle as O
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     mid = rays_cpu.shape[0] // 2
     rays = rays_cpu[mid:mid + n_rays]

@@ -102,6 +102,7 @@ extern "C" int nerf_amd_launch_composite(const float* raw, const float* ts, cons
                                          long long dirs_stride, float* rgb, float* disp, float* alpha,
                                          float* acc, float* w, long long B, int N, int normalize_dirs,
                                          hipStream_t stream) {
+    (void)hipGetLastError();   // drop any stale error: the return value is about THIS launch
     if (B == 0) return 0;
     const long long blocks = (B + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
     hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_BLOCK), 0, stream,

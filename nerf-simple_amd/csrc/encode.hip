@@ -64,6 +64,7 @@ __host__ int grid_for(long long total) {
 
 extern "C" int nerf_amd_launch_gamma(const float* x, long long x_stride, float* out, long long n,
                                      int L, hipStream_t stream) {
+    (void)hipGetLastError();   // drop any stale error: the return value is about THIS launch
     if (n == 0 || L == 0) return 0;
     hipLaunchKernelGGL(gamma_kernel, dim3(grid_for(n * 2 * L)), dim3(256), 0, stream, x, x_stride, out, n, L);
     return (int)hipGetLastError();
@@ -71,6 +72,7 @@ extern "C" int nerf_amd_launch_gamma(const float* x, long long x_stride, float* 
 
 extern "C" int nerf_amd_launch_posenc(const float* vec, float* posx, float* posd, long long P,
                                       int Lp, int Ld, hipStream_t stream) {
+    (void)hipGetLastError();   // drop any stale error: the return value is about THIS launch
     if (P == 0) return 0;
     hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(P * (6 + 6 * Lp + 6 * Ld))), dim3(256), 0, stream,
                        vec, posx, posd, P, Lp, Ld);

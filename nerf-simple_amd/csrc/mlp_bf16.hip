@@ -361,6 +361,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bf16_kernel(Ml
 }  // namespace
 
 extern "C" int nerf_amd_launch_mlp_bf16(const MlpArgs* args, int rays_mode, hipStream_t stream) {
+    (void)hipGetLastError();   // drop any stale error: the return value is about THIS launch
     MlpArgs a = *args;
     if (a.P <= 0) return 0;
     const long long ntiles = (a.P + TILE_PTS - 1) / TILE_PTS;

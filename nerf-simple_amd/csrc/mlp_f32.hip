@@ -261,6 +261,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_f32_kernel(Mlp
 }  // namespace
 
 extern "C" int nerf_amd_launch_mlp_f32(const MlpArgs* args, int rays_mode, hipStream_t stream) {
+    (void)hipGetLastError();   // drop any stale error: the return value is about THIS launch
     MlpArgs a = *args;
     if (a.P <= 0) return 0;
     const long long ntiles = (a.P + TILE_PTS - 1) / TILE_PTS;

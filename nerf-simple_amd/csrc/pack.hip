@@ -68,6 +68,7 @@ __global__ void pack_bias_kernel(const float* __restrict__ params, float* __rest
 }  // namespace
 
 extern "C" int nerf_amd_launch_pack(const float* params, void* packed, int precision, hipStream_t stream) {
+    (void)hipGetLastError();   // drop any stale error: the return value is about THIS launch
     if (precision == 1) {
         hipLaunchKernelGGL(pack_bf16_kernel, dim3(1024), dim3(256), 0, stream, params,
                            reinterpret_cast<__bf16*>(packed));
