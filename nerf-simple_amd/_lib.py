@@ -8,6 +8,13 @@ import ctypes
 import os
 import threading
 
+# torch must be imported BEFORE the library is dlopen'ed: torch ships its own
+# HIP runtime (torch/lib/libamdhip64.so) and device pointers only mean something
+# inside the runtime that allocated them.  Loaded first, that runtime also
+# satisfies libnerf_amd.so's libamdhip64 dependency; loaded second, the process
+# would hold two runtimes and every launch would fail with hipErrorNoDevice.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
 
@@ -81,7 +88,6 @@ def ptr(t):
 
 
 def stream_ptr(device):
-    import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
@@ -89,7 +95,6 @@ def require_cuda_f32(t, name):
     """The kernels take fp32, contiguous, device-resident tensors; anything
     else is an error (the reference's callers do .cuda() themselves,
     utils/rendering.py:102, train.py:51)."""
-    import torch
     if not torch.is_tensor(t):
         raise AssertionError(f"{name} needs to be a torch tensor")
     if not t.is_cuda:
