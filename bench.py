@@ -115,11 +115,11 @@ def main():
     pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
     rays_cpu = camera_rays([pose], [H, W, synthetic.focal_from_fov(W)])       # [640000, 6]
     n_rays = rays_cpu.shape[0]
-    lo, hi = rank * n_rays // world, (rank + 1) * n_rays // world
+    from nerf_simple_amd import parallel
+    lo, hi = parallel.shard_range(n_rays, rank, world)
     rays = rays_cpu[lo:hi].to(dev).contiguous()
     shard = torch.empty((hi - lo, 4), dtype=torch.float32, device=dev)
     image = torch.empty((n_rays, 4), dtype=torch.float32, device=dev) if world > 1 else shard
-    equal_shards = n_rays % world == 0
     events = []
 
     def step(record):
@@ -130,11 +130,7 @@ def main():
             shard[:, :3] = torch.clip(rgb, 0., 1.)
             shard[:, 3] = disp
             if world > 1:
-                if equal_shards:
-                    dist.all_gather_into_tensor(image, shard)
-                else:
-                    parts = [image[r * n_rays // world:(r + 1) * n_rays // world] for r in range(world)]
-                    dist.all_gather(parts, shard)
+                parallel.gather_pixels(shard, n_rays, out=image)     # ONE RCCL all-gather per image
 
     def fence():
         if world > 1:

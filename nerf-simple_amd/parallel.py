@@ -1,0 +1,106 @@
+"""Multi-GPU layer: one process per GPU, torch.distributed (backend "nccl" is
+RCCL over xGMI on ROCm; "gloo" on CPU in the tests).
+
+The reference has no distributed code at all; this is
+new.  The render path shards by RAYS -- every ray is independent through
+sampling, MLP and compositing (reference utils/rendering.py:13-85 has no
+cross-ray op) -- so the data path needs no collective.  Two exchanges exist:
+
+  * full-image renders: ONE all-gather of the packed [rgb, disparity] pixels
+    (16 B/ray; 1.28 MB per rank for 800x800 on 8 GPUs, latency-bound);
+  * training: ONE all-reduce of the flattened gradient (595,844 fp32 = 2.38 MB).
+
+Jitter is indexed by GLOBAL ray id (explicit ``u`` rows, or the counter RNG's
+``ray_id0``), so an image does not depend on the number of ranks.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+def shard_range(n, rank, world):
+    """Contiguous, balanced range of rank ``rank``: [lo, hi)."""
+    return rank * n // world, (rank + 1) * n // world
+
+
+def gather_pixels(shard, n_total, group=None, out=None):
+    """All-gather per-rank pixel shards [n_r, C] (contiguous ranges in rank
+    order, from shard_range) into the full [n_total, C] table on every rank.
+    Equal shards use one all_gather_into_tensor; ragged ones are padded to the
+    largest shard so it is still a single collective."""
+    rank, world = world_info(group)
+    if world == 1:
+        return shard if out is None else out.copy_(shard)
+    C = shard.shape[1]
+    if out is None:
+        out = torch.empty((n_total, C), dtype=shard.dtype, device=shard.device)
+    if n_total % world == 0:
+        dist.all_gather_into_tensor(out, shard.contiguous(), group=group)
+        return out
+    sizes = [shard_range(n_total, r, world) for r in range(world)]
+    m = max(hi - lo for lo, hi in sizes)
+    padded = torch.zeros((m, C), dtype=shard.dtype, device=shard.device)
+    padded[:shard.shape[0]] = shard
+    buf = torch.empty((world * m, C), dtype=shard.dtype, device=shard.device)
+    dist.all_gather_into_tensor(buf, padded, group=group)
+    for r, (lo, hi) in enumerate(sizes):
+        out[lo:hi] = buf[r * m:r * m + (hi - lo)]
+    return out
+
+
+def render_image_sharded(rays, render_fn, group=None, u=None):
+    """rays [n,6] (the same full table on every rank) -> (rgb [n,3] clipped to
+    [0,1], disparity [n]) on every rank.
+
+    render_fn(rays_shard, u_shard, ray_id0) -> (rgb [m,3], disp [m]) renders one
+    shard; in production it is the HIP path (rendering._render_batched), the
+    gloo tests inject the CPU oracle.  Clipping happens AFTER compositing, the
+    disparity is left un-clipped (reference utils/rendering.py:103-105)."""
+    rank, world = world_info(group)
+    n = rays.shape[0]
+    lo, hi = shard_range(n, rank, world)
+    rgb, disp = render_fn(rays[lo:hi], None if u is None else u[lo:hi], lo)
+    shard = torch.cat([torch.clip(rgb, 0., 1.), disp.reshape(-1, 1)], dim=1)
+    full = gather_pixels(shard, n, group)
+    return full[:, :3], full[:, 3]
+
+
+def allreduce_gradients(params, group=None):
+    """Average gradients over data-parallel replicas with ONE collective: the
+    grads are flattened into a single contiguous bucket (2.38 MB for the NeRF
+    MLP), all-reduced (sum), divided by the world size and scattered back.
+    With equal per-rank batch sizes and a per-rank MSE mean, the result is the
+    gradient of the global-batch MSE (reference train.py:52-54)."""
+    rank, world = world_info(group)
+    params = [p for p in params if p.grad is not None]
+    if world == 1 or not params:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat /= world
+    off = 0
+    for p in params:
+        k = p.grad.numel()
+        p.grad.copy_(flat[off:off + k].view_as(p.grad))
+        off += k
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Make every replica start from rank ``src``'s weights (one flat broadcast)."""
+    rank, world = world_info(group)
+    if world == 1:
+        return
+    ps = list(module.parameters())
+    flat = torch.cat([p.detach().reshape(-1) for p in ps])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    with torch.no_grad():
+        for p in ps:
+            k = p.numel()
+            p.copy_(flat[off:off + k].view_as(p))
+            off += k

@@ -228,3 +228,20 @@ def render_poses(net, poses, cam_params, batch_size, savepath='', *, N=128, tn=2
         rgb_imgs.append(rgb.cpu().reshape(H, W, 3).numpy())
         disp_imgs.append(disp.cpu().reshape(H, W).numpy())
     return rgb_imgs, disp_imgs
+
+
+def render_rays_sharded(net, rays, batch_size, *, N=128, tn=2, tf=6, u=None, group=None, **kw):
+    """Multi-GPU full-image render (BASELINE config 4's data path): every rank
+    holds the same ray table [n,6] (any device), renders its contiguous share
+    with the HIP path and all-gathers the packed [rgb, disparity] pixels
+    (nerf_simple_amd.parallel).  Returns (rgb [n,3] clipped, disparity [n]) on
+    every rank's GPU.  Jitter is indexed by global ray id, so the image does
+    not depend on the number of ranks."""
+    from .. import parallel
+    dev = next(net.parameters()).device
+
+    def render_fn(r, us, ray_id0):
+        return _render_batched(r.to(dev).float().contiguous(), net, batch_size, N, tn, tf,
+                               None if us is None else us.to(dev), False, id_base=ray_id0, **kw)
+
+    return parallel.render_image_sharded(rays, render_fn, group=group, u=u)
