@@ -35,7 +35,7 @@ extern "C" {
 #define NERF_AMD_EUNSUP   (-2)   /* unsupported configuration */
 
 /* precision of the fused MLP */
-#define NERF_AMD_F32   0   /* exact-f32 MFMA (v_mfma_f32_32x32x2_f32), fp32 end to end */
+#define NERF_AMD_F32   0   /* exact-f32 MFMA (v_mfma_f32_16x16x4_f32), fp32 end to end */
 #define NERF_AMD_BF16  1   /* bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
 
 /* flags of nerf_amd_render_forward / nerf_amd_mlp_forward_rays */
@@ -89,6 +89,16 @@ int nerf_amd_volume_render(const float* raw, const float* ts,
                            float* rgb, float* disp, float* alpha, float* acc, float* w,
                            int64_t B, int N, void* stream);
 
+/* Backward of the above: d loss / d raw [B,N,4] from the upstream gradients of
+ * the five outputs (any of g_* may be NULL = zero).  Autograd through
+ * volume_render in the training step, reference train.py:51-54.  ts and dirs
+ * get no gradient (they carry none in the reference either).  N <= 512. */
+int nerf_amd_volume_render_backward(const float* raw, const float* ts,
+                                    const float* dirs, int64_t dirs_stride,
+                                    const float* g_rgb, const float* g_disp, const float* g_alpha,
+                                    const float* g_acc, const float* g_w,
+                                    float* d_raw, int64_t B, int N, void* stream);
+
 /* ---- the whole path: render_nerf, utils/rendering.py:13-45 ------------------- */
 /* rays[B,6] = [origin, direction] -> (rgb[B,3], disp[B], alpha[B,N], acc[B], w[B,N]).
  *   u        jitter in [0,1) [B,N] exactly as the reference draws it with
@@ -113,6 +123,15 @@ int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tb
                               const void* packed, int precision, uint32_t flags,
                               uint64_t seed, int64_t ray_id0,
                               float* raw, float* ts, int64_t B, int N, void* stream);
+
+/* Training-side front end: sampling + point assembly + encoding in one launch
+ * (utils/rendering.py:24-40 + utils/xyz.py:16-36): rays[B,6] (+ u / ts / device
+ * RNG as in nerf_amd_render_forward) -> posx[B*N,63], posd[B*N,27], ts[B,N]
+ * (Lp = 10, Ld = 4).  Feeds the dense layers when their backward runs through
+ * library GEMMs. */
+int nerf_amd_sample_encode(const float* rays, const float* u, const float* tbins,
+                           uint32_t flags, uint64_t seed, int64_t ray_id0,
+                           float* posx, float* posd, float* ts, int64_t B, int N, void* stream);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,10 @@ int nerf_amd_launch_gamma(const float*, long long, float*, long long, int, hipSt
 int nerf_amd_launch_posenc(const float*, float*, float*, long long, int, int, hipStream_t);
 int nerf_amd_launch_composite(const float*, const float*, const float*, long long, float*, float*,
                               float*, float*, float*, long long, int, int, hipStream_t);
+int nerf_amd_launch_composite_backward(const float*, const float*, const float*, long long, const float*,
+                                       const float*, const float*, const float*, const float*, float*,
+                                       long long, int, int, hipStream_t);
+int nerf_amd_launch_sample_encode(const MlpArgs*, float*, float*, hipStream_t);
 int nerf_amd_launch_mlp_bf16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
 }
@@ -132,6 +136,32 @@ int nerf_amd_volume_render(const float* raw, const float* ts, const float* dirs,
     if (B == 0) return 0;
     if (!raw || !ts || !dirs || !rgb || !disp || !acc) return NERF_AMD_EINVAL;
     return nerf_amd_launch_composite(raw, ts, dirs, dirs_stride, rgb, disp, alpha, acc, w, B, N, 0, S(stream));
+}
+
+int nerf_amd_volume_render_backward(const float* raw, const float* ts, const float* dirs, int64_t dirs_stride,
+                                    const float* g_rgb, const float* g_disp, const float* g_alpha,
+                                    const float* g_acc, const float* g_w, float* d_raw, int64_t B, int N,
+                                    void* stream) {
+    if (B < 0 || N <= 0 || dirs_stride < 3) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (N > 512) return NERF_AMD_EUNSUP;
+    if (!raw || !ts || !dirs || !d_raw) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_composite_backward(raw, ts, dirs, dirs_stride, g_rgb, g_disp, g_alpha, g_acc, g_w,
+                                              d_raw, B, N, 0, S(stream));
+}
+
+int nerf_amd_sample_encode(const float* rays, const float* u, const float* tbins, uint32_t flags,
+                           uint64_t seed, int64_t ray_id0, float* posx, float* posd, float* ts, int64_t B,
+                           int N, void* stream) {
+    if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (!rays || !posx || !posd) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+    MlpArgs a{};
+    a.rays = rays; a.u = u; a.tbins = tbins; a.ts_out = ts;
+    a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
+    return nerf_amd_launch_sample_encode(&a, posx, posd, S(stream));
 }
 
 int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tbins, const void* packed,

@@ -96,7 +96,145 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_kernel(
     }
 }
 
+// ---- backward ---------------------------------------------------------------
+// d loss / d nerf_outs[B,N,4] given the upstream gradients of the five outputs
+// (NULL = zero).  With G_i = dL/dw_i gathered from every consumer of w,
+//   dL/dc_i     = w_i * g_rgb
+//   dL/dalpha_i = G_i T_i - (1/f_i) * sum_{k>i} G_k w_k + g_alpha_i       (f = 1 - alpha + 1e-10)
+//   dL/dsigma_i = dL/dalpha_i * (1 - alpha_i) * delta_i * softplus'(sigma_i)
+// The suffix sum over k > i is a wave-level reverse scan; chunks of 64 samples
+// are walked forward once (recomputing alpha, T, w) and backward once.
+constexpr int MAX_CHUNKS = 8;          // N <= 512
+
+__device__ __forceinline__ float wave_suffix_excl(float v, int lane, float& total) {
+    // inclusive suffix sum, then shift down by one lane
+    float incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float dn = __shfl_down(incl, off);
+        if (lane + off < 64) incl += dn;
+    }
+    total = __shfl(incl, 0);
+    float ex = __shfl_down(incl, 1);
+    if (lane == 63) ex = 0.f;
+    return ex;
+}
+
+__global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_backward_kernel(
+    const float* __restrict__ raw, const float* __restrict__ ts, const float* __restrict__ dirs,
+    long long dirs_stride, const float* __restrict__ g_rgb, const float* __restrict__ g_disp,
+    const float* __restrict__ g_alpha, const float* __restrict__ g_acc, const float* __restrict__ g_w,
+    float* __restrict__ d_raw, long long B, int N, int normalize_dirs) {
+    const long long ray = (long long)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= B) return;
+    const int lane = threadIdx.x & 63;
+    const float* d = dirs + ray * dirs_stride;
+    float d0 = d[0], d1 = d[1], d2 = d[2];
+    if (normalize_dirs) {
+        const float n = norm3(d0, d1, d2);
+        d0 = __fdiv_rn(d0, n); d1 = __fdiv_rn(d1, n); d2 = __fdiv_rn(d2, n);
+    }
+    const float dnorm = norm3(d0, d1, d2);
+    const float* rts = ts + ray * N;
+    const f32x4* rraw = reinterpret_cast<const f32x4*>(raw) + ray * N;
+    f32x4* rout = reinterpret_cast<f32x4*>(d_raw) + ray * N;
+
+    // forward sweep: per chunk keep alpha, T, fac, delta*softplus' and the colour
+    float al[MAX_CHUNKS], Tt[MAX_CHUNKS], fc[MAX_CHUNKS], ds[MAX_CHUNKS], tt[MAX_CHUNKS];
+    f32x4 cc[MAX_CHUNKS];
+    float carry = 1.0f, depth = 0.f, accw = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < MAX_CHUNKS; ++ch) {
+        const int base = ch * 64;
+        al[ch] = 0.f; Tt[ch] = 0.f; fc[ch] = 1.f; ds[ch] = 0.f; tt[ch] = 0.f;
+        cc[ch] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (base < N) {
+            const int i = base + lane;
+            const bool valid = i < N;
+            float a = 0.f, fac = 1.0f;
+            if (valid) {
+                const float t = rts[i];
+                const f32x4 c = rraw[i];
+                float delta = (i == N - 1) ? 1e10f : __fsub_rn(rts[i + 1], t);
+                delta = __fmul_rn(delta, dnorm);
+                const float sigma = c[3];
+                const float sp = sigma > 20.f ? sigma : log1pf(expf(sigma));
+                const float spd = sigma > 20.f ? 1.0f : 1.0f / (1.0f + expf(-sigma));
+                a = __fsub_rn(1.0f, expf(__fmul_rn(-sp, delta)));
+                fac = __fadd_rn(__fsub_rn(1.0f, a), 1e-10f);
+                ds[ch] = (1.0f - a) * delta * spd;       // d alpha / d sigma
+                tt[ch] = t; cc[ch] = c;
+            }
+            float incl = fac;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const float up = __shfl_up(incl, off);
+                if (lane >= off) incl *= up;
+            }
+            float excl = __shfl_up(incl, 1);
+            if (lane == 0) excl = 1.0f;
+            al[ch] = a; fc[ch] = fac; Tt[ch] = carry * excl;
+            carry *= __shfl(incl, 63);
+            if (valid) { depth += a * Tt[ch] * tt[ch]; accw += a * Tt[ch]; }
+        }
+    }
+    depth = wave_sum(depth); accw = wave_sum(accw);
+
+    // upstream gradients that reach every w_i of the ray
+    const float gr = g_rgb ? g_rgb[ray * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f,
+                gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+    float gdep = 0.f, gac = g_acc ? g_acc[ray] : 0.f;
+    if (g_disp) {
+        const float q = depth / accw;
+        if (q > 1e-10f) {                        // disp = 1/q there; the clamp branch has zero slope
+            const float dq = -g_disp[ray] / (q * q);
+            gdep = dq / accw;
+            gac += -dq * depth / (accw * accw);
+        }
+    }
+    // backward sweep over chunks, carrying sum_{k in later chunks} G_k w_k
+    float later = 0.f;
+#pragma unroll
+    for (int ch = MAX_CHUNKS - 1; ch >= 0; --ch) {
+        const int base = ch * 64;
+        if (base < N) {
+            const int i = base + lane;
+            const bool valid = i < N;
+            const float w = al[ch] * Tt[ch];
+            float G = 0.f;
+            if (valid) {
+                G = gr * cc[ch][0] + gg * cc[ch][1] + gb * cc[ch][2] + gdep * tt[ch] + gac;
+                if (g_w) G += g_w[ray * N + i];
+            }
+            float tot;
+            const float suffix = wave_suffix_excl(valid ? G * w : 0.f, lane, tot) + later;
+            later += tot;
+            if (valid) {
+                float dalpha = G * Tt[ch] - suffix / fc[ch];
+                if (g_alpha) dalpha += g_alpha[ray * N + i];
+                const f32x4 o = {w * gr, w * gg, w * gb, dalpha * ds[ch]};
+                rout[i] = o;
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int nerf_amd_launch_composite_backward(const float* raw, const float* ts, const float* dirs,
+                                                  long long dirs_stride, const float* g_rgb,
+                                                  const float* g_disp, const float* g_alpha,
+                                                  const float* g_acc, const float* g_w, float* d_raw,
+                                                  long long B, int N, int normalize_dirs, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B == 0) return 0;
+    if (N > 64 * MAX_CHUNKS) return -2;
+    const long long blocks = (B + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
+    hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_BLOCK), 0, stream,
+                       raw, ts, dirs, dirs_stride, g_rgb, g_disp, g_alpha, g_acc, g_w, d_raw, B, N,
+                       normalize_dirs);
+    return (int)hipGetLastError();
+}
 
 extern "C" int nerf_amd_launch_composite(const float* raw, const float* ts, const float* dirs,
                                          long long dirs_stride, float* rgb, float* disp, float* alpha,

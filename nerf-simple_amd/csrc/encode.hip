@@ -55,6 +55,29 @@ __global__ void posenc_kernel(const float* __restrict__ vec, float* __restrict__
     }
 }
 
+// Training-side front end: sampling + point assembly + encoding in one pass
+// (reference utils/rendering.py:24-40 + utils/xyz.py:16-36), writing the
+// encoder outputs the dense layers consume: posx[P,63], posd[P,27], ts[B,N].
+// One thread per output element of the concatenated [63 | 27] row.
+__global__ void sample_encode_kernel(MlpArgs a, float* __restrict__ posx, float* __restrict__ posd) {
+    constexpr int Cx = 63, Cd = 27, C = Cx + Cd;
+    const long long total = a.P * C;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long p = e / C;
+        int col = (int)(e - p * C);
+        const PointIn pt = fetch_point_rays(a, p);
+        if (col == 0 && a.ts_out) a.ts_out[p] = pt.t;
+        const float xyz[3] = {pt.x, pt.y, pt.z}, dd[3] = {pt.d1, pt.d2, pt.d3};
+        if (col < Cx) {
+            posx[p * Cx + col] = col < 3 ? xyz[col] : enc_value(xyz[(col - 3) / 20], (col - 3) % 20);
+        } else {
+            col -= Cx;
+            posd[p * Cd + col] = col < 3 ? dd[col] : enc_value(dd[(col - 3) / 8], (col - 3) % 8);
+        }
+    }
+}
+
 __host__ int grid_for(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 256 * 32 ? 256 * 32 : g));
@@ -76,5 +99,12 @@ extern "C" int nerf_amd_launch_posenc(const float* vec, float* posx, float* posd
     if (P == 0) return 0;
     hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(P * (6 + 6 * Lp + 6 * Ld))), dim3(256), 0, stream,
                        vec, posx, posd, P, Lp, Ld);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nerf_amd_launch_sample_encode(const MlpArgs* args, float* posx, float* posd, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (args->P == 0) return 0;
+    hipLaunchKernelGGL(sample_encode_kernel, dim3(grid_for(args->P * 90)), dim3(256), 0, stream, *args, posx, posd);
     return (int)hipGetLastError();
 }

@@ -1,11 +1,26 @@
-"""Training-side entry points (reference train.py:16-26,41-57): autograd
-wrappers around the HIP forward/backward kernels, loss/PSNR helpers.
+"""Training-side entry points: the step of reference train.py:47-57 on the GPU.
 
-The backward kernels are not built yet; until they are, asking for gradients
-through the fused path raises instead of silently returning tensors without a
-grad_fn.
+What runs where in a training step (BASELINE config 5):
+
+  sampling + point assembly + positional encoding   HIP  nerf_amd_sample_encode
+  12 dense layers, forward and backward             library GEMMs (hipBLASLt / rocBLAS through
+                                                    torch.nn.functional.linear under autograd),
+                                                    bf16 operands via autocast or plain fp32
+  sigma -> alpha compositing, forward               HIP  nerf_amd_volume_render
+  compositing, backward (suffix-sum scan)           HIP  nerf_amd_volume_render_backward
+  gradient exchange                                 RCCL all-reduce of one flat bucket (parallel.py)
+  optimizer                                         torch.optim.Adam (reference train.py:43)
+
+The dense layers' backward is a set of plain GEMMs (dW = dY^T X over the point
+dimension, dX = dY W), which is what the vendor library is for; a fused
+hand-written backward that keeps the dX chain on-chip like the forward kernel
+is the planned replacement.  Inference never comes here:
+without gradients the fused forward kernel runs (utils/nets.py, utils/rendering.py).
 """
 import torch
+import torch.nn.functional as F
+
+from . import _lib
 
 
 def img_mse(gt, pred):
@@ -24,19 +39,119 @@ def img_psnr(gt, pred):
     return 20 * torch.log(torch.max(gt)) / torch.log(ten) - 10 * torch.log(img_mse(gt, pred)) / torch.log(ten)
 
 
-def _not_built(what):
-    raise NotImplementedError(
-        f"{what}: the HIP backward kernels are not built yet; wrap inference calls in "
-        "torch.no_grad() (as the reference's render_image does, utils/rendering.py:99)")
+# --------------------------------------------------------------------------
+# compositor with a HIP backward
+# --------------------------------------------------------------------------
+class _VolumeRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, ts, dirs):
+        B, N = raw.shape[0], raw.shape[1]
+        dev = raw.device
+        raw, ts, dirs = raw.contiguous(), ts.contiguous(), dirs.contiguous()
+        rgb = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        disp = torch.empty((B,), dtype=torch.float32, device=dev)
+        acc = torch.empty((B,), dtype=torch.float32, device=dev)
+        alpha = torch.empty((B, N), dtype=torch.float32, device=dev)
+        w = torch.empty((B, N), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().nerf_amd_volume_render(
+                _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(dirs), 3, _lib.ptr(rgb), _lib.ptr(disp),
+                _lib.ptr(alpha), _lib.ptr(acc), _lib.ptr(w), B, N, _lib.stream_ptr(dev)),
+                "nerf_amd_volume_render")
+        ctx.save_for_backward(raw, ts, dirs)
+        return rgb, disp, alpha, acc, w
 
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_alpha, g_acc, g_w):
+        raw, ts, dirs = ctx.saved_tensors
+        B, N = raw.shape[0], raw.shape[1]
+        dev = raw.device
+        d_raw = torch.empty_like(raw)
 
-def nerf_forward_autograd(net, v, precision):
-    _not_built("Nerf.forward with gradients")
+        def c(g):
+            return None if g is None else g.contiguous().float()
+        g_rgb, g_disp, g_alpha, g_acc, g_w = map(c, (g_rgb, g_disp, g_alpha, g_acc, g_w))
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().nerf_amd_volume_render_backward(
+                _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(dirs), 3, _lib.ptr(g_rgb), _lib.ptr(g_disp),
+                _lib.ptr(g_alpha), _lib.ptr(g_acc), _lib.ptr(g_w), _lib.ptr(d_raw), B, N,
+                _lib.stream_ptr(dev)), "nerf_amd_volume_render_backward")
+        return d_raw, None, None
 
 
 def volume_render_autograd(nerf_outs, ts, dirs):
-    _not_built("volume_render with gradients")
+    """volume_render (reference utils/rendering.py:47-85) with gradients to
+    nerf_outs; ts and dirs get none (they carry none in the reference either)."""
+    return _VolumeRender.apply(nerf_outs.float(), ts.detach(), dirs.detach())
+
+
+# --------------------------------------------------------------------------
+# the dense layers under autograd (library GEMMs)
+# --------------------------------------------------------------------------
+def _dense_layers(net, x, d, precision):
+    """Data-flow of reference utils/nets.py:37-43 on already-encoded inputs,
+    through the module's own nn.Linear parameters so autograd reaches them."""
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(_lib.precision_code(precision) == _lib.BF16)):
+        h = net.layers_0(x)
+        h = net.skip_conn_layer(torch.cat([h, x.to(h.dtype)], dim=1))
+        h = net.layers_1(h)
+        sigma = net.sigma_fc(h)
+        h = net.layers_2(h)
+        rgb = net.color_fc(torch.cat([h, d.to(h.dtype)], dim=1))
+        return torch.cat([rgb, sigma], dim=1).float()
+
+
+def nerf_forward_autograd(net, v, precision):
+    """Nerf.forward with gradients to the parameters: HIP encoder + library GEMMs."""
+    from .utils.xyz import positional_encoder
+    x, d = positional_encoder(v.detach(), net.Lp, net.Ld)
+    return _dense_layers(net, x, d, precision)
 
 
 def render_nerf_autograd(rays, net, N, tn, tf, jit, flags, precision, seed, ray_id0):
-    _not_built("render_nerf with gradients")
+    """render_nerf (reference utils/rendering.py:13-45) with gradients to the
+    parameters of ``net``; returns the same 5-tuple."""
+    from .utils.rendering import _tbins
+    B, dev = rays.size(0), rays.device
+    lib = _lib.lib()
+    P = B * N
+    posx = torch.empty((P, 63), dtype=torch.float32, device=dev)
+    posd = torch.empty((P, 27), dtype=torch.float32, device=dev)
+    ts = torch.empty((B, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nerf_amd_sample_encode(
+            _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)), flags, int(seed), int(ray_id0),
+            _lib.ptr(posx), _lib.ptr(posd), _lib.ptr(ts), B, N, _lib.stream_ptr(dev)),
+            "nerf_amd_sample_encode")
+    out = _dense_layers(net, posx, posd, precision).reshape(B, N, 4)
+    dn = rays[:, 3:] / torch.norm(rays[:, 3:], dim=1, keepdim=True)
+    return _VolumeRender.apply(out, ts, dn)
+
+
+# --------------------------------------------------------------------------
+# one optimisation step (reference train.py:47-57)
+# --------------------------------------------------------------------------
+def lr_decay_factor(lr_init, lr_final, num_iters):
+    """Per-iteration multiplicative decay (reference train.py:36-39)."""
+    import math
+    return math.exp(math.log(lr_final / lr_init) / num_iters)
+
+
+def train_step(net, optimizer, rays, gt, N, *, tn=2, tf=6, u=None, decay=1.0, group=None,
+               precision=None, device_rng=False, seed=0, ray_id0=0):
+    """zero_grad -> render_nerf -> MSELoss(rgb, gt) -> backward -> [grad all-reduce]
+    -> optimizer.step -> lr *= decay.  Returns the (detached) loss.
+    Only ``rgb`` feeds the loss, as in the reference (train.py:52)."""
+    from . import parallel
+    from .utils.rendering import render_nerf
+    optimizer.zero_grad(set_to_none=False)
+    rgb, _, _, _, _ = render_nerf(rays, net, N, tn, tf, u=u, precision=precision,
+                                  device_rng=device_rng, seed=seed, ray_id0=ray_id0)
+    loss = F.mse_loss(rgb, gt)
+    loss.backward()
+    parallel.allreduce_gradients(net.parameters(), group=group)
+    optimizer.step()
+    if decay != 1.0:
+        for pg in optimizer.param_groups:
+            pg["lr"] = pg["lr"] * decay
+    return loss.detach()

@@ -63,7 +63,7 @@ class Nerf(nn.Module):
         first use and again after any in-place parameter update / reassignment."""
         if not self._fused_ok():
             raise RuntimeError("the fused HIP path is built for Nerf(Lp=10, Ld=4, H=256) only")
-        code = _lib.precision_code(precision or self.precision)
+        code = _lib.precision_code(self.precision if precision is None else precision)
         params = self._param_list()
         dev = params[0].device
         if dev.type != "cuda":
@@ -92,11 +92,11 @@ class Nerf(nn.Module):
             raise RuntimeError("Nerf.forward expects a [P, 6] tensor")
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from ..training import nerf_forward_autograd
-            return nerf_forward_autograd(self, v, precision or self.precision)
+            return nerf_forward_autograd(self, v, self.precision if precision is None else precision)
         return self.forward_inference(v, precision=precision)
 
     def forward_inference(self, v, *, precision=None):
-        code = _lib.precision_code(precision or self.precision)
+        code = _lib.precision_code(self.precision if precision is None else precision)
         packed = self.packed_weights(code)
         v = v.detach().contiguous()
         P = v.shape[0]

@@ -112,12 +112,13 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
     training = fused and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
     if training:
         from ..training import render_nerf_autograd
-        return render_nerf_autograd(rays, net, N, tn, tf, jit, flags, precision or net.precision,
+        return render_nerf_autograd(rays, net, N, tn, tf, jit, flags,
+                                    net.precision if precision is None else precision,
                                     seed, ray_id0)
     if not fused:
         return _render_generic(rays, net, N, tn, tf, jit, flags, outputs, seed, ray_id0)
 
-    code = _lib.precision_code(precision or net.precision)
+    code = _lib.precision_code(net.precision if precision is None else precision)
     packed = net.packed_weights(code)
     lib = _lib.lib()
     rgb = torch.empty((B, 3), dtype=torch.float32, device=dev)

@@ -357,3 +357,20 @@ def test_large_batch_properties(dev, synthetic):
     T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1 - alpha + 1e-10], 1), 1)[:, :-1]
     assert torch.allclose(w, alpha * T, rtol=1e-4, atol=1e-7)
     assert (acc <= 1 + 1e-5).all() and (acc > 0).all()
+
+
+def test_precision_override(dev, golden, synthetic):
+    """precision= on the call overrides the module default (and fp32's code is 0:
+    a falsy value must not fall back to the default)."""
+    from nerf_simple_amd.utils.rendering import render_nerf
+    g = golden("render_structured.npz")
+    net = make_net(synthetic, dev, "structured", "bf16")
+    rays, u = t(g["rays"]).to(dev), t(g["N64_u"]).to(dev)
+    with torch.no_grad():
+        a = render_nerf(rays, net, 64, u=u, precision="fp32")
+        b = render_nerf(rays, net, 64, u=u)
+        v = t(golden("mlp_structured.npz")["v"]).to(dev)
+        o32 = net.forward(v, precision="fp32")
+    assert scaled_err(a[0].cpu().numpy(), g["N64_rgb"]) <= F32_TOL
+    assert F32_TOL < scaled_err(b[0].cpu().numpy(), g["N64_rgb"]) <= BF16_TOL
+    assert scaled_err(o32.cpu().numpy(), golden("mlp_structured.npz")["out"]) <= F32_TOL
