@@ -124,6 +124,36 @@ int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tb
                               uint64_t seed, int64_t ray_id0,
                               float* raw, float* ts, int64_t B, int N, void* stream);
 
+/* ---- image drivers: render_poses / render_image, utils/rendering.py:88-153 ---- */
+/* Pinhole rays on the device (utils/xyz.py:38-52 + utils/rendering.py:129-134):
+ * rays[i] = [pose[:3,3], pose[:3,:3] @ ((w-W//2)/f, -(h-H//2)/f, -1)] for pixel
+ * p = ray0 + i = h*W + w.  h_pose: HOST pointer to a row-major 3x4 / 4x4 pose. */
+int nerf_amd_generate_rays(const float* h_pose, int H, int W, float f,
+                           int64_t ray0, int64_t n_rays, float* rays, void* stream);
+int64_t nerf_amd_render_image_workspace_bytes(int64_t n_rays, int N);
+/* One call = the body of the reference's per-image loop (utils/rendering.py:139-151)
+ * for pixels [ray0, ray0+n_rays) of an HxW view: ray generation, render_nerf,
+ * clip(rgb,0,1) after compositing, disparity un-clipped ->
+ * pixels[n_rays,4] = [r,g,b,disparity].  Three launches, no host sync; the
+ * multi-GPU driver calls it per rank and all-gathers `pixels`.  u / tbins /
+ * flags / seed as in nerf_amd_render_forward (u indexed from ray0). */
+int nerf_amd_render_image_forward(const float* h_pose, int H, int W, float f,
+                                  int64_t ray0, int64_t n_rays,
+                                  const float* u, const float* tbins,
+                                  const void* packed, int precision, uint32_t flags, uint64_t seed,
+                                  float* pixels, void* workspace, int N, void* stream);
+
+/* ---- hierarchical sampling (BASELINE config 4) -------------------------------- */
+/* ABSENT from the reference (README.md:3, configs/lego.yaml:7): parity unpinned.
+ * Inverse-CDF placement of Nf new samples from the coarse pass's weights (the
+ * NeRF paper's sample_pdf over interior bins), merged and sorted with the Nc
+ * coarse positions: ts[B,Nc], w[B,Nc], u[B,Nf] in [0,1) (or NERF_AMD_DEVICE_RNG)
+ * -> ts_out[B,Nc+Nf] ascending.  Feed ts_out to nerf_amd_render_forward with
+ * NERF_AMD_TS_GIVEN for the fine pass.  3 <= Nc <= 256, Nc+Nf <= 512. */
+int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u,
+                        uint32_t flags, uint64_t seed, int64_t ray_id0,
+                        float* ts_out, int64_t B, int Nc, int Nf, void* stream);
+
 /* Training-side front end: sampling + point assembly + encoding in one launch
  * (utils/rendering.py:24-40 + utils/xyz.py:16-36): rays[B,6] (+ u / ts / device
  * RNG as in nerf_amd_render_forward) -> posx[B*N,63], posd[B*N,27], ts[B,N]

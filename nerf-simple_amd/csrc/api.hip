@@ -11,7 +11,10 @@ int nerf_amd_launch_pack(const float*, void*, int, hipStream_t);
 int nerf_amd_launch_gamma(const float*, long long, float*, long long, int, hipStream_t);
 int nerf_amd_launch_posenc(const float*, float*, float*, long long, int, int, hipStream_t);
 int nerf_amd_launch_composite(const float*, const float*, const float*, long long, float*, float*,
-                              float*, float*, float*, long long, int, int, hipStream_t);
+                              float*, float*, float*, long long, int, int, float*, hipStream_t);
+int nerf_amd_launch_sample_pdf(const float*, const float*, const float*, float*, long long, int, int,
+                               unsigned long long, long long, int, hipStream_t);
+int nerf_amd_launch_generate_rays(const float*, int, int, float, long long, long long, float*, hipStream_t);
 int nerf_amd_launch_composite_backward(const float*, const float*, const float*, long long, const float*,
                                        const float*, const float*, const float*, const float*, float*,
                                        long long, int, int, hipStream_t);
@@ -40,6 +43,12 @@ int64_t nerf_amd_packed_bytes(int precision) {
     if (bad_precision(precision)) return NERF_AMD_EINVAL;
     // + slack so that the staging loads of the last chunks stay inside the allocation
     return (precision == NERF_AMD_BF16 ? BF16_PACKED_BYTES : F32_PACKED_BYTES);
+}
+
+int64_t nerf_amd_render_image_workspace_bytes(int64_t n_rays, int N) {
+    if (n_rays < 0 || N <= 0) return NERF_AMD_EINVAL;
+    // rays[n,6] + raw[n,N,4] + ts[n,N]
+    return align_up(n_rays * 24, 256) + align_up(n_rays * N * 16, 256) + align_up(n_rays * N * 4, 256);
 }
 
 int64_t nerf_amd_render_workspace_bytes(int64_t B, int N) {
@@ -135,7 +144,7 @@ int nerf_amd_volume_render(const float* raw, const float* ts, const float* dirs,
     if (B < 0 || N <= 0 || dirs_stride < 3) return NERF_AMD_EINVAL;
     if (B == 0) return 0;
     if (!raw || !ts || !dirs || !rgb || !disp || !acc) return NERF_AMD_EINVAL;
-    return nerf_amd_launch_composite(raw, ts, dirs, dirs_stride, rgb, disp, alpha, acc, w, B, N, 0, S(stream));
+    return nerf_amd_launch_composite(raw, ts, dirs, dirs_stride, rgb, disp, alpha, acc, w, B, N, 0, nullptr, S(stream));
 }
 
 int nerf_amd_volume_render_backward(const float* raw, const float* ts, const float* dirs, int64_t dirs_stride,
@@ -191,7 +200,47 @@ int nerf_amd_render_forward(const float* rays, const float* u, const float* tbin
                                        stream);
     if (rc) return rc;
     // dirs = rays[:,3:] normalised inside the kernel (utils/rendering.py:37,43)
-    return nerf_amd_launch_composite(raw, ts, rays + 3, 6, rgb, disp, alpha, acc, w, B, N, 1, S(stream));
+    return nerf_amd_launch_composite(raw, ts, rays + 3, 6, rgb, disp, alpha, acc, w, B, N, 1, nullptr, S(stream));
+}
+
+int nerf_amd_generate_rays(const float* h_pose, int H, int W, float f, int64_t ray0, int64_t n_rays,
+                           float* rays, void* stream) {
+    if (!h_pose || H <= 0 || W <= 0 || !(f > 0.f) || ray0 < 0 || n_rays < 0 ||
+        ray0 + n_rays > (int64_t)H * W) return NERF_AMD_EINVAL;
+    if (n_rays == 0) return 0;
+    if (!rays) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_generate_rays(h_pose, H, W, f, ray0, n_rays, rays, S(stream));
+}
+
+int nerf_amd_render_image_forward(const float* h_pose, int H, int W, float f, int64_t ray0, int64_t n_rays,
+                                  const float* u, const float* tbins, const void* packed, int precision,
+                                  uint32_t flags, uint64_t seed, float* pixels, void* workspace, int N,
+                                  void* stream) {
+    if (n_rays < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
+    if (n_rays == 0) return 0;
+    if (!workspace || !pixels || !packed) return NERF_AMD_EINVAL;
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* rays = reinterpret_cast<float*>(ws);
+    float* raw = reinterpret_cast<float*>(ws + align_up(n_rays * 24, 256));
+    float* ts = reinterpret_cast<float*>(ws + align_up(n_rays * 24, 256) + align_up(n_rays * N * 16, 256));
+    int rc = nerf_amd_generate_rays(h_pose, H, W, f, ray0, n_rays, rays, stream);
+    if (rc) return rc;
+    // jitter is keyed by the GLOBAL pixel id, so the image does not depend on how it is sharded
+    rc = nerf_amd_mlp_forward_rays(rays, u, tbins, packed, precision, flags, seed, ray0, raw, ts, n_rays, N, stream);
+    if (rc) return rc;
+    return nerf_amd_launch_composite(raw, ts, rays + 3, 6, nullptr, nullptr, nullptr, nullptr, nullptr, n_rays, N,
+                                     1, pixels, S(stream));
+}
+
+int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u, uint32_t flags, uint64_t seed,
+                        int64_t ray_id0, float* ts_out, int64_t B, int Nc, int Nf, void* stream) {
+    if (B < 0 || Nc <= 0 || Nf < 0) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (Nc < 3 || Nc > 256 || Nc + Nf > 512) return NERF_AMD_EUNSUP;
+    if (!ts || !w || !ts_out) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_DEVICE_RNG) && !u && Nf > 0) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_sample_pdf(ts, w, u, ts_out, B, Nc, Nf, seed, ray_id0,
+                                      (flags & NERF_AMD_DEVICE_RNG) ? 1 : 0, S(stream));
 }
 
 }  // extern "C"

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_kernel(
     const float* __restrict__ raw, const float* __restrict__ ts, const float* __restrict__ dirs,
     long long dirs_stride, float* __restrict__ rgb, float* __restrict__ disp,
     float* __restrict__ alpha, float* __restrict__ acc, float* __restrict__ w, long long B, int N,
-    int normalize_dirs) {
+    int normalize_dirs, float* __restrict__ pixels) {
     const long long ray = (long long)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= B) return;                      // whole wave leaves together; no barriers below
     const int lane = threadIdx.x & 63;
@@ -86,13 +86,19 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_kernel(
     sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb);
     sd = wave_sum(sd); sa = wave_sum(sa);
     if (lane == 0) {
-        rgb[ray * 3 + 0] = sr;
-        rgb[ray * 3 + 1] = sg;
-        rgb[ray * 3 + 2] = sb;
-        acc[ray] = sa;
         const float q = __fdiv_rn(sd, sa);
         const float m = (q != q) ? q : fmaxf(1e-10f, q);   // torch.max propagates NaN
-        disp[ray] = __fdiv_rn(1.0f, m);
+        const float dsp = __fdiv_rn(1.0f, m);
+        if (rgb) { rgb[ray * 3 + 0] = sr; rgb[ray * 3 + 1] = sg; rgb[ray * 3 + 2] = sb; }
+        if (acc) acc[ray] = sa;
+        if (disp) disp[ray] = dsp;
+        if (pixels) {
+            // image-driver epilogue (utils/rendering.py:103-105): clip rgb to [0,1]
+            // AFTER compositing (torch.clip passes NaN through), disparity un-clipped
+            auto clip01 = [](float v) { return (v != v) ? v : fminf(fmaxf(v, 0.f), 1.f); };
+            const f32x4 px = {clip01(sr), clip01(sg), clip01(sb), dsp};
+            *reinterpret_cast<f32x4*>(pixels + ray * 4) = px;
+        }
     }
 }
 
@@ -239,11 +245,11 @@ extern "C" int nerf_amd_launch_composite_backward(const float* raw, const float*
 extern "C" int nerf_amd_launch_composite(const float* raw, const float* ts, const float* dirs,
                                          long long dirs_stride, float* rgb, float* disp, float* alpha,
                                          float* acc, float* w, long long B, int N, int normalize_dirs,
-                                         hipStream_t stream) {
+                                         float* pixels, hipStream_t stream) {
     (void)hipGetLastError();   // drop any stale error: the return value is about THIS launch
     if (B == 0) return 0;
     const long long blocks = (B + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
     hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_BLOCK), 0, stream,
-                       raw, ts, dirs, dirs_stride, rgb, disp, alpha, acc, w, B, N, normalize_dirs);
+                       raw, ts, dirs, dirs_stride, rgb, disp, alpha, acc, w, B, N, normalize_dirs, pixels);
     return (int)hipGetLastError();
 }

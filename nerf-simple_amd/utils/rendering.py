@@ -246,3 +246,129 @@ def render_rays_sharded(net, rays, batch_size, *, N=128, tn=2, tf=6, u=None, gro
                                None if us is None else us.to(dev), False, id_base=ray_id0, **kw)
 
     return parallel.render_image_sharded(rays, render_fn, group=group, u=u)
+
+
+def generate_rays(pose, cam_params, device, ray0=0, n_rays=None):
+    """Pinhole rays of an HxW view on the GPU (reference utils/xyz.py:38-52 +
+    utils/rendering.py:129-134 run on the CPU): pose [4,4] or [3,4] (host tensor /
+    array), cam_params [H,W,f] -> rays [n_rays,6] for pixels ray0.. in row-major
+    order."""
+    import numpy as np
+    H, W, f = int(cam_params[0]), int(cam_params[1]), float(cam_params[2])
+    n = H * W - ray0 if n_rays is None else int(n_rays)
+    h_pose = np.ascontiguousarray(np.asarray(pose, dtype=np.float32)[:3, :4])
+    h_pose4 = np.zeros((3, 4), dtype=np.float32)
+    h_pose4[:] = h_pose
+    rays = torch.empty((n, 6), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(_lib.lib().nerf_amd_generate_rays(
+            h_pose4.ctypes.data, H, W, f, int(ray0), n, _lib.ptr(rays), _lib.stream_ptr(device)),
+            "nerf_amd_generate_rays")
+    return rays
+
+
+def render_view(net, pose, cam_params, *, N=128, tn=2, tf=6, u=None, ray0=0, n_rays=None,
+                precision=None, device_rng=False, seed=0):
+    """One view (or the pixel range [ray0, ray0+n_rays) of it) in ONE library
+    call: device ray generation -> render_nerf -> clip(rgb,0,1), i.e. the body of
+    the reference's per-image loop (utils/rendering.py:139-151) without the
+    Python batch loop.  Returns pixels [n,4] = [r,g,b,disparity] on the GPU.
+    ``u`` [n,N] explicit jitter for these pixels; default: one CPU
+    torch.rand(n,N) like the reference; device_rng=True: counter RNG keyed by
+    global pixel id."""
+    import numpy as np
+    dev = next(net.parameters()).device
+    H, W, f = int(cam_params[0]), int(cam_params[1]), float(cam_params[2])
+    n = H * W - ray0 if n_rays is None else int(n_rays)
+    code = _lib.precision_code(net.precision if precision is None else precision)
+    packed = net.packed_weights(code)
+    flags, jit = 0, None
+    if u is not None:
+        jit = _lib.require_cuda_f32(u, "u").contiguous()
+    elif device_rng:
+        flags = _lib.FLAG_DEVICE_RNG
+    else:
+        jit = torch.rand(n, N).to(dev)
+    lib = _lib.lib()
+    h_pose = np.zeros((3, 4), dtype=np.float32)
+    h_pose[:] = np.asarray(pose, dtype=np.float32)[:3, :4]
+    pixels = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    ws = torch.empty(max(int(lib.nerf_amd_render_image_workspace_bytes(n, N)), 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nerf_amd_render_image_forward(
+            h_pose.ctypes.data, H, W, f, int(ray0), n, _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)),
+            _lib.ptr(packed), code, flags, int(seed), _lib.ptr(pixels), _lib.ptr(ws), int(N),
+            _lib.stream_ptr(dev)), "nerf_amd_render_image_forward")
+    return pixels
+
+
+def render_view_sharded(net, pose, cam_params, *, group=None, **kw):
+    """Multi-GPU render_view: rank r renders its contiguous pixel range and ONE
+    all-gather assembles pixels [H*W,4] on every rank (BASELINE config 4)."""
+    from .. import parallel
+    rank, world = parallel.world_info(group)
+    n = int(cam_params[0]) * int(cam_params[1])
+    lo, hi = parallel.shard_range(n, rank, world)
+    u = kw.pop("u", None)
+    shard = render_view(net, pose, cam_params, ray0=lo, n_rays=hi - lo,
+                        u=None if u is None else u[lo:hi], **kw)
+    return parallel.gather_pixels(shard, n, group)
+
+
+def sample_pdf(ts, w, Nf, *, u=None, device_rng=False, seed=0, ray_id0=0):
+    """Importance sampling for a fine pass (BASELINE config 4; NOT in the
+    reference -- parity unpinned, follows the NeRF paper): ts [B,Nc] coarse
+    positions, w [B,Nc] coarse weights -> sorted [B,Nc+Nf] positions (the coarse
+    ones plus Nf inverse-CDF samples).  u [B,Nf] explicit uniforms; default one
+    CPU torch.rand(B,Nf); device_rng=True: counter RNG."""
+    _lib.require_cuda_f32(ts, "ts")
+    _lib.require_cuda_f32(w, "w")
+    B, Nc = ts.shape
+    dev = ts.device
+    flags, jit = 0, None
+    if u is not None:
+        jit = _lib.require_cuda_f32(u, "u").contiguous()
+    elif device_rng:
+        flags = _lib.FLAG_DEVICE_RNG
+    else:
+        jit = torch.rand(B, Nf).to(dev)
+    out = torch.empty((B, Nc + Nf), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().nerf_amd_sample_pdf(
+            _lib.ptr(ts.contiguous()), _lib.ptr(w.contiguous()), _lib.ptr(jit), flags, int(seed), int(ray_id0),
+            _lib.ptr(out), B, int(Nc), int(Nf), _lib.stream_ptr(dev)), "nerf_amd_sample_pdf")
+    return out
+
+
+def render_hierarchical(rays, net_coarse, net_fine, Nc=64, Nf=128, tn=2, tf=6, *, u_c=None, u_f=None,
+                        precision=None, device_rng=False, seed=0, ray_id0=0):
+    """Coarse + fine render (BASELINE config 4: 64 + 128 samples).  The reference
+    only has the single-pass render_nerf (its CoarseNet / FineNet are empty
+    classes), so this composition is new: a coarse render_nerf pass with Nc
+    stratified samples, sample_pdf on its weights, and a second render_nerf pass
+    of ``net_fine`` on the merged Nc+Nf positions (explicit ts).  Each pass is the
+    pinned render_nerf; only the sampler in between is unpinned.
+    Returns (fine 5-tuple, coarse 5-tuple, ts_fine)."""
+    _lib.require_cuda_f32(rays, "rays")
+    dev, B = rays.device, rays.size(0)
+    if u_c is None and not device_rng:
+        u_c = torch.rand(B, Nc).to(dev)
+    if u_c is not None:
+        tb = _tbins(tn, tf, Nc, dev)
+        ts_c = (tb[1] - tb[0]) * u_c + tb[:-1]
+        coarse = render_nerf(rays, net_coarse, Nc, tn, tf, ts=ts_c, precision=precision)
+    else:
+        # device RNG: recover the positions the kernel drew through the stage-1 entry point
+        code = _lib.precision_code(net_coarse.precision if precision is None else precision)
+        raw = torch.empty((B, Nc, 4), dtype=torch.float32, device=dev)
+        ts_c = torch.empty((B, Nc), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().nerf_amd_mlp_forward_rays(
+                _lib.ptr(rays.contiguous()), None, _lib.ptr(_tbins(tn, tf, Nc, dev)),
+                _lib.ptr(net_coarse.packed_weights(code)), code, _lib.FLAG_DEVICE_RNG, int(seed), int(ray_id0),
+                _lib.ptr(raw), _lib.ptr(ts_c), B, Nc, _lib.stream_ptr(dev)), "nerf_amd_mlp_forward_rays")
+        dn = rays[:, 3:] / torch.norm(rays[:, 3:], dim=1, keepdim=True)
+        coarse = volume_render(raw, ts_c, dn.contiguous())
+    ts_f = sample_pdf(ts_c, coarse[4], Nf, u=u_f, device_rng=device_rng, seed=seed, ray_id0=ray_id0)
+    fine = render_nerf(rays, net_fine, Nc + Nf, tn, tf, ts=ts_f, precision=precision)
+    return fine, coarse, ts_f

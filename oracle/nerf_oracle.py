@@ -13,6 +13,12 @@ tests/golden/make_golden.py (which holds no reference code).  The reference
 pins torch==1.11.0 (requirements.txt:2); only torch 2.10.0 exists offline, so
 the goldens are "reference source on torch 2.10 CPU" (SURVEY.md section 8c).
 
+EXCEPTION -- parity UNPINNED: ``sample_pdf`` / ``render_hierarchical`` (BASELINE
+config 4's fine pass).  Hierarchical sampling does not exist in the reference
+(README.md:3, configs/lego.yaml:7, utils/nets.py:45-49), so there is nothing to
+capture goldens from; they restate the NeRF paper and only the two constituent
+render passes are pinned (through render_nerf with explicit ts).
+
 Each function cites the reference file:line it restates.
 """
 import math
@@ -131,6 +137,40 @@ def render_nerf(rays, sd, N, tn=2, tf=6, u=None, ts=None):
     q, dn = query_points(rays, ts)
     out = nerf_forward(sd, q).reshape(B, N, 4)
     return volume_render(out, ts, dn)
+
+
+# --------------------------------------------------------------------------
+# hierarchical sampling -- NOT in the reference (README.md:3; configs/lego.yaml:7;
+# utils/nets.py:45-49): PARITY UNPINNED.  Restates the NeRF paper's sample_pdf
+# (Mildenhall et al. 2020, section 5.2) so the HIP sampler has a checker.
+# --------------------------------------------------------------------------
+def sample_pdf(ts, w, u):
+    """ts [B,Nc] coarse positions, w [B,Nc] coarse weights, u [B,Nf] in [0,1)
+    -> sorted [B,Nc+Nf]: Nf inverse-CDF samples of the interior bins
+    (mids of ts, weights w[1:-1] + 1e-5) merged with ts."""
+    bins = 0.5 * (ts[:, 1:] + ts[:, :-1])
+    wt = w[:, 1:-1] + 1e-5
+    pdf = wt / torch.sum(wt, -1, keepdim=True)
+    cdf = torch.cat([torch.zeros_like(pdf[:, :1]), torch.cumsum(pdf, -1)], -1)
+    inds = torch.searchsorted(cdf, u.contiguous(), right=True)
+    below = torch.clamp(inds - 1, min=0)
+    above = torch.clamp(inds, max=cdf.shape[-1] - 1)
+    c0, c1 = torch.gather(cdf, 1, below), torch.gather(cdf, 1, above)
+    b0, b1 = torch.gather(bins, 1, below), torch.gather(bins, 1, above)
+    denom = c1 - c0
+    denom = torch.where(denom < 1e-5, torch.ones_like(denom), denom)
+    z = b0 + (u - c0) / denom * (b1 - b0)
+    return torch.sort(torch.cat([ts, z], -1), -1).values
+
+
+def render_hierarchical(rays, sd_coarse, sd_fine, Nc, Nf, u_c, u_f, tn=2, tf=6):
+    """Coarse pass (Nc stratified samples) -> sample_pdf -> fine pass on the
+    Nc+Nf merged positions.  Returns (fine 5-tuple, coarse 5-tuple, ts_fine)."""
+    ts_c = sample_ts(u_c, tn, tf)
+    coarse = render_nerf(rays, sd_coarse, Nc, tn, tf, ts=ts_c)
+    ts_f = sample_pdf(ts_c, coarse[4], u_f)
+    fine = render_nerf(rays, sd_fine, Nc + Nf, tn, tf, ts=ts_f)
+    return fine, coarse, ts_f
 
 
 # --------------------------------------------------------------------------

@@ -374,3 +374,96 @@ def test_precision_override(dev, golden, synthetic):
     assert scaled_err(a[0].cpu().numpy(), g["N64_rgb"]) <= F32_TOL
     assert F32_TOL < scaled_err(b[0].cpu().numpy(), g["N64_rgb"]) <= BF16_TOL
     assert scaled_err(o32.cpu().numpy(), golden("mlp_structured.npz")["out"]) <= F32_TOL
+
+
+def test_generate_rays_golden(dev, golden):
+    """N1: device ray generation == the reference's CPU ray table (to fma rounding
+    of the 3-term rotation, which MKL may associate differently)."""
+    from nerf_simple_amd.utils.rendering import generate_rays
+    g = golden("camera.npz")
+    f = float(g["f"])
+    rays = generate_rays(g["pose_4_m30_40"], [100, 100, f], dev).cpu().numpy()
+    assert rays.shape == (10000, 6)
+    assert np.array_equal(rays[:, :3], g["rays100_phi40"][:, :3])
+    np.testing.assert_allclose(rays[:, 3:], g["rays100_phi40"][:, 3:], rtol=0, atol=2.4e-7)
+    part = generate_rays(g["pose_4_m30_40"], [100, 100, f], dev, ray0=4321, n_rays=77).cpu().numpy()
+    assert np.array_equal(part, rays[4321:4398])
+
+
+@pytest.mark.parametrize("kind", ["default", "structured"])
+def test_render_view_golden(dev, golden, synthetic, kind):
+    """N2: one-call view render == golden G5 image (rays generated on the device,
+    clip after compositing, disparity un-clipped), whole and in pixel ranges."""
+    from nerf_simple_amd.utils.rendering import render_view
+    g = golden(f"image_{kind}.npz")
+    u = t(golden("image_u.npz")["u"]).to(dev)
+    net = make_net(synthetic, dev, kind, "fp32")
+    cam = [100, 100, synthetic.focal_from_fov(100)]
+    with torch.no_grad():
+        px = render_view(net, g["pose"], cam, N=32, u=u)
+        a = render_view(net, g["pose"], cam, N=32, u=u[:3333], ray0=0, n_rays=3333)
+        b = render_view(net, g["pose"], cam, N=32, u=u[3333:], ray0=3333)
+    assert px.shape == (10000, 4)
+    assert scaled_err(px[:, :3].cpu().numpy(), g["rgb"]) <= F32_TOL
+    assert scaled_err(px[:, 3].cpu().numpy(), g["disp"]) <= F32_TOL
+    assert torch.equal(torch.cat([a, b]), px)
+    # device RNG: sharding-invariant
+    with torch.no_grad():
+        full = render_view(net, g["pose"], cam, N=32, device_rng=True, seed=5, precision="bf16")
+        parts = [render_view(net, g["pose"], cam, N=32, device_rng=True, seed=5, precision="bf16",
+                             ray0=s, n_rays=2500) for s in range(0, 10000, 2500)]
+    assert torch.equal(torch.cat(parts), full)
+
+
+def test_sample_pdf_vs_oracle(dev, oracle):
+    """A9 (parity UNPINNED: no reference code exists): the HIP sampler against the
+    oracle's restatement of the NeRF paper's sample_pdf."""
+    from nerf_simple_amd.utils.rendering import sample_pdf
+    gen = torch.Generator().manual_seed(31)
+    for B, Nc, Nf in ((64, 64, 128), (7, 32, 64), (5, 128, 100), (3, 256, 256)):
+        u_c = torch.rand(B, Nc, generator=gen)
+        ts = oracle.sample_ts(u_c)
+        w = torch.rand(B, Nc, generator=gen) ** 4           # peaky weights
+        w[0] = 0.0                                          # an empty ray: uniform pdf via the 1e-5 floor
+        u = torch.rand(B, Nf, generator=gen)
+        want = oracle.sample_pdf(ts, w, u)
+        got = sample_pdf(ts.to(dev), w.to(dev), Nf, u=u.to(dev)).cpu()
+        assert got.shape == (B, Nc + Nf)
+        assert (got[:, 1:] >= got[:, :-1]).all(), "positions must be sorted"
+        # (u - c0)/denom amplifies fp32 rounding of the cdf where a bin's mass is tiny
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=0, atol=1e-4)
+    # device RNG: new samples inside [first mid, last mid], deterministic
+    a = sample_pdf(ts.to(dev), w.to(dev), 64, device_rng=True, seed=3)
+    b = sample_pdf(ts.to(dev), w.to(dev), 64, device_rng=True, seed=3)
+    assert torch.equal(a, b) and (a[:, 1:] >= a[:, :-1]).all()
+
+
+def test_render_hierarchical(dev, oracle, synthetic, golden):
+    """Config 4 shape (64 coarse + 128 fine): both passes are the pinned
+    render_nerf; compare the composition against the oracle's."""
+    from nerf_simple_amd.utils.rendering import render_hierarchical
+    g = golden("render_structured.npz")
+    rays = t(g["rays"])[:64]
+    sd_c = synthetic.synthetic_state_dict(0, "structured")
+    sd_f = synthetic.synthetic_state_dict(7, "structured")
+    u_c, u_f = t(g["N64_u"])[:64], torch.rand(64, 128, generator=torch.Generator().manual_seed(8))
+    with torch.no_grad():
+        wf, wc, wts = oracle.render_hierarchical(rays, sd_c, sd_f, 64, 128, u_c, u_f)
+    from nerf_simple_amd.utils.nets import Nerf
+    nc, nf = Nerf(precision="fp32").to(dev), Nerf(precision="fp32").to(dev)
+    nc.load_state_dict(sd_c)
+    nf.load_state_dict(sd_f)
+    with torch.no_grad():
+        fine, coarse, ts_f = render_hierarchical(rays.to(dev), nc, nf, 64, 128, u_c=u_c.to(dev), u_f=u_f.to(dev))
+    assert ts_f.shape == (64, 192)
+    # the GPU's coarse weights differ from the CPU's in the last bits and the inverse cdf
+    # amplifies that where the pdf is nearly flat: compare in distribution
+    dts = (ts_f.cpu() - wts).abs()
+    assert float((dts <= 5e-4).float().mean()) >= 0.995 and float(dts.max()) <= 2e-2
+    assert scaled_err(coarse[0].cpu().numpy(), wc[0].numpy()) <= F32_TOL
+    # the fine pass sees slightly different positions (sampler rounding): looser
+    assert scaled_err(fine[0].cpu().numpy(), wf[0].numpy()) <= 5e-3
+    assert scaled_err(fine[3].cpu().numpy(), wf[3].numpy()) <= 5e-3
+    with torch.no_grad():
+        f2, _, t2 = render_hierarchical(rays.to(dev), nc, nf, 64, 128, device_rng=True, seed=4, precision="bf16")
+    assert t2.shape == (64, 192) and torch.isfinite(f2[0]).all()

@@ -80,9 +80,14 @@ def test_train_step_golden_fp32(dev, golden, synthetic):
         post = p.detach().cpu().numpy()
         wantp = g[f"post/{k}"] if f"post/{k}" in g.files else g[f"postc/{k}"]
         gotp = post if f"post/{k}" in g.files else post[:16, :16]
-        # the first Adam step moves each weight by ~lr * sign(grad): entries whose
-        # gradient is ~0 may flip, everything else agrees to fp32 rounding
-        assert np.mean(np.abs(gotp - wantp) <= 2e-7) >= 0.98, k
+        # first Adam step: update = lr * g / (|g| + eps), eps = 1e-8.  Where |g| is
+        # not small against eps the update is ~lr*sign(g) and must agree to fp32
+        # rounding; entries with |g| ~ eps amplify the (1e-3 relative) gradient
+        # difference and are only bounded by the step size.
+        solid = np.abs(want) > 1e-6
+        if solid.any():
+            assert np.abs(gotp - wantp)[solid].max() <= 1e-6, k
+        assert np.abs(gotp - wantp).max() <= 2 * 5e-4, k
 
 
 def test_nerf_forward_autograd(dev, oracle, synthetic):
