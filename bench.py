@@ -3,8 +3,8 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-One step = one full 800x800 single-view render with 128 samples per ray through
-render_nerf (sampling + encoding + fused bf16 MLP + compositing), 640,000 rays
+One step = one full 800x800 single-view render with 128 samples per ray (the two
+launches of render_nerf: sampling + encoding + fused bf16 MLP, then compositing + clip), 640,000 rays
 x 128 = 81.92 M ray-samples, synthetic camera and generator-seeded weights
 (SURVEY.md section 8d), jitter from the device counter RNG, every input
 resident in HBM before the timed region.  With N > 1 the rays of the image are
@@ -118,33 +118,54 @@ def main():
     from nerf_simple_amd import parallel
     lo, hi = parallel.shard_range(n_rays, rank, world)
     rays = rays_cpu[lo:hi].to(dev).contiguous()
-    shard = torch.empty((hi - lo, 4), dtype=torch.float32, device=dev)
+    # every buffer of a step is allocated once, outside the timed region
+    lib = _lib.lib()
+    nr = hi - lo
+    code = _lib.precision_code(args.precision)
+    packed = net.packed_weights(code)
+    tbins = torch.linspace(2, 6, N_SAMPLES + 1).to(dev)
+    raw = torch.empty((nr, N_SAMPLES, 4), dtype=torch.float32, device=dev)
+    ts = torch.empty((nr, N_SAMPLES), dtype=torch.float32, device=dev)
+    shard = torch.empty((nr, 4), dtype=torch.float32, device=dev)
     image = torch.empty((n_rays, 4), dtype=torch.float32, device=dev) if world > 1 else shard
     events = []
 
     def step(record):
-        with torch.no_grad():
-            rgb, disp, _, _, _ = render_nerf(rays, net, N_SAMPLES, device_rng=True, seed=1234, ray_id0=lo,
-                                             outputs=("rgb", "disp", "acc"),
-                                             stage_events=events if record else None)
-            shard[:, :3] = torch.clip(rgb, 0., 1.)
-            shard[:, 3] = disp
-            if world > 1:
-                parallel.gather_pixels(shard, n_rays, out=image)     # ONE RCCL all-gather per image
+        # the two launches of nerf_amd_render_forward / render_nerf, through the C ABI
+        # (sampling + encoding + fused MLP, then compositing + clip), then the all-gather
+        st = _lib.stream_ptr(dev)
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _lib.check(lib.nerf_amd_mlp_forward_rays(
+            _lib.ptr(rays), None, _lib.ptr(tbins), _lib.ptr(packed), code, _lib.FLAG_DEVICE_RNG, 1234, lo,
+            _lib.ptr(raw), _lib.ptr(ts), nr, N_SAMPLES, st), "nerf_amd_mlp_forward_rays")
+        if record:
+            e1.record()
+            events.append((e0, e1))
+        _lib.check(lib.nerf_amd_volume_render_pixels(
+            _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(rays), _lib.ptr(shard), nr, N_SAMPLES, st),
+            "nerf_amd_volume_render_pixels")
+        if world > 1:
+            parallel.gather_pixels(shard, n_rays, out=image)     # ONE RCCL all-gather per image
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    import gc
     for _ in range(args.warmup):
         step(False)
+    gc.collect()
+    gc.disable()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -157,7 +178,7 @@ def main():
         peak = PEAK_BF16 if args.precision == "bf16" else PEAK_F32
         launch_samples = (hi - lo) * N_SAMPLES
         achieved = launch_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12
-        kern = "nerf_mlp_bf16_kernel<true>" if args.precision == "bf16" else "nerf_mlp_f32_kernel<true>"
+        kern = "nerf_mlp_bf16_16_kernel<true>" if args.precision == "bf16" else "nerf_mlp_f32_kernel<true>"
         res = {
             "metric": "ray-samples/sec at 800x800x128", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

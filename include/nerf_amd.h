@@ -89,6 +89,12 @@ int nerf_amd_volume_render(const float* raw, const float* ts,
                            float* rgb, float* disp, float* alpha, float* acc, float* w,
                            int64_t B, int N, void* stream);
 
+/* Image-driver form of the compositor (stage 2 of nerf_amd_render_image_forward
+ * on its own): raw[B,N,4], ts[B,N] from nerf_amd_mlp_forward_rays and the same
+ * rays[B,6] -> pixels[B,4] = [clip(rgb,0,1), disparity]  (utils/rendering.py:102-105). */
+int nerf_amd_volume_render_pixels(const float* raw, const float* ts, const float* rays,
+                                  float* pixels, int64_t B, int N, void* stream);
+
 /* Backward of the above: d loss / d raw [B,N,4] from the upstream gradients of
  * the five outputs (any of g_* may be NULL = zero).  Autograd through
  * volume_render in the training step, reference train.py:51-54.  ts and dirs

@@ -3,6 +3,11 @@
 // out of the kernels in this directory.  No allocation, no host sync.
 #include "nerf_device.h"
 #include "../../include/nerf_amd.h"
+#include <stdlib.h>
+
+#ifndef NERF_AMD_DEFAULT_BF16_TILE
+#define NERF_AMD_DEFAULT_BF16_TILE 16
+#endif
 
 using namespace nerf_layout;
 
@@ -21,6 +26,7 @@ int nerf_amd_launch_composite_backward(const float*, const float*, const float*,
 int nerf_amd_launch_sample_encode(const MlpArgs*, float*, float*, hipStream_t);
 int nerf_amd_launch_mlp_bf16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
+int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
 }
 
 namespace {
@@ -28,9 +34,17 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool bad_precision(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// bf16 has two MFMA-shape variants of the same kernel (32x32x16 and 16x16x32);
+// NERF_AMD_BF16_TILE=32|16 picks one per call (read each time: cheap, and it lets
+// one process A/B both on the same device).
+int bf16_tile() {
+    const char* e = getenv("NERF_AMD_BF16_TILE");
+    return (e && e[0] == '3') ? 32 : (e && e[0] == '1') ? 16 : NERF_AMD_DEFAULT_BF16_TILE;
+}
 int launch_mlp(const MlpArgs& a, int rays_mode, int precision, hipStream_t s) {
-    return precision == NERF_AMD_BF16 ? nerf_amd_launch_mlp_bf16(&a, rays_mode, s)
-                                      : nerf_amd_launch_mlp_f32(&a, rays_mode, s);
+    if (precision != NERF_AMD_BF16) return nerf_amd_launch_mlp_f32(&a, rays_mode, s);
+    return bf16_tile() == 16 ? nerf_amd_launch_mlp_bf16_16(&a, rays_mode, s)
+                             : nerf_amd_launch_mlp_bf16(&a, rays_mode, s);
 }
 }  // namespace
 
@@ -42,7 +56,7 @@ int64_t nerf_amd_param_count(void) { return PARAM_COUNT; }
 int64_t nerf_amd_packed_bytes(int precision) {
     if (bad_precision(precision)) return NERF_AMD_EINVAL;
     // + slack so that the staging loads of the last chunks stay inside the allocation
-    return (precision == NERF_AMD_BF16 ? BF16_PACKED_BYTES : F32_PACKED_BYTES);
+    return (precision == NERF_AMD_BF16 ? BF16_PACKED_TOTAL_BYTES : F32_PACKED_BYTES);
 }
 
 int64_t nerf_amd_render_image_workspace_bytes(int64_t n_rays, int N) {
@@ -76,6 +90,22 @@ int nerf_amd_layout_selfcheck(void) {
     static_assert(BF16_WEIGHT_KIB == 1192, "bf16 image size");
     static_assert(BIAS_FLOATS == 2496, "bias table size");
     static_assert(F32_NUM_CHUNKS == 154, "f32 chunk count");
+    static_assert(B16_WEIGHT_KIB == 1172 && B16_BIAS_FLOATS == F32_BIAS_FLOATS, "16-row bf16 image");
+    for (int L = 0; L < NUM_LAYERS; ++L) {          // 16-row bf16 tiling: same bijection property
+        const LayerDesc d = layer_desc(L);
+        int seen[320] = {0}, pads = 0;
+        for (int s = 0; s < b16_ks(L); ++s)
+            for (int g = 0; g < 4; ++g)
+                for (int j = 0; j < 8; ++j) {
+                    const int c = src_col_b16(L, s, g, j);
+                    if (c < 0) { ++pads; continue; }
+                    if (c >= d.ld) return 500 + L;
+                    ++seen[c];
+                }
+        for (int i = 0; i < d.ld; ++i)
+            if (seen[i] != 1) return 520 + L;
+        if (pads != layer_k(L) - d.ld) return 540 + L;
+    }
     for (int L = 0; L < NUM_LAYERS; ++L) {
         const LayerDesc d = layer_desc(L);
         int seen[320];
@@ -145,6 +175,15 @@ int nerf_amd_volume_render(const float* raw, const float* ts, const float* dirs,
     if (B == 0) return 0;
     if (!raw || !ts || !dirs || !rgb || !disp || !acc) return NERF_AMD_EINVAL;
     return nerf_amd_launch_composite(raw, ts, dirs, dirs_stride, rgb, disp, alpha, acc, w, B, N, 0, nullptr, S(stream));
+}
+
+int nerf_amd_volume_render_pixels(const float* raw, const float* ts, const float* rays, float* pixels,
+                                  int64_t B, int N, void* stream) {
+    if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (!raw || !ts || !rays || !pixels) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_composite(raw, ts, rays + 3, 6, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, 1,
+                                     pixels, S(stream));
 }
 
 int nerf_amd_volume_render_backward(const float* raw, const float* ts, const float* dirs, int64_t dirs_stride,

@@ -1,0 +1,378 @@
+// mlp_bf16_16.hip -- the fused bf16 MLP on v_mfma_f32_16x16x32_bf16.
+//
+// Same algorithm, tile and dataflow as mlp_bf16.hip (read its header first);
+// only the MFMA shape differs: 16-row output tiles, a wave's 32 points are two
+// 16-point column blocks, 64 lanes = 16 points x 4 lane groups.  The chip is
+// power/DVFS-limited on this kernel and holds a higher
+// clock on the 16x16x32 shape than on 32x32x16 at equal cycles per FLOP
+// (MI355X_MICROARCH.md, DVFS give-back item 7), so this variant exists to be
+// A/B'd against the 32x32x16 one on the same device.
+//
+//   * two stacked 16-row accumulator tiles (2q, 2q+1), converted to bf16, ARE
+//     the B fragment of the next layer's k-step q (32 features);
+//   * one weight fragment read from LDS (16 rows x 32 k, 1 KiB) feeds two
+//     MFMAs (the two column blocks): the same LDS bytes per FLOP;
+//   * the sigma head costs one 16-row tile and the rgb head 8 MFMAs (half of
+//     the 32-row variant's padding).
+#include "nerf_device.h"
+#include <utility>
+
+using namespace nerf_layout;
+
+namespace {
+
+constexpr int WAVES = 8;
+constexpr int TILE_PTS = WAVES * 32;
+constexpr int TPC = 4;                        // 16-row output tiles per weight chunk (64 rows)
+
+__host__ __device__ constexpr int layer_chunks(int L) { return (b16_mt(L) + TPC - 1) / TPC; }
+__host__ __device__ constexpr int chunk_first(int L) {
+    int c = 0;
+    for (int i = 0; i < L; ++i) c += layer_chunks(i);
+    return c;
+}
+constexpr int NUM_CHUNKS = chunk_first(NUM_LAYERS);           // 40
+__host__ __device__ constexpr int chunk_layer(int cc) {
+    int L = 0;
+    while (cc >= layer_chunks(L)) { cc -= layer_chunks(L); ++L; }
+    return L;
+}
+__host__ __device__ constexpr int chunk_tiles(int cc) {
+    const int L = chunk_layer(cc), C = cc - chunk_first(L);
+    const int left = b16_mt(L) - C * TPC;
+    return left < TPC ? left : TPC;
+}
+__host__ __device__ constexpr int chunk_kib(int cc) { return chunk_tiles(cc) * b16_ks(chunk_layer(cc)); }
+__host__ __device__ constexpr int chunk_off_kib(int cc) {
+    const int L = chunk_layer(cc), C = cc - chunk_first(L);
+    return b16_layer_off_kib(L) + C * TPC * b16_ks(L);
+}
+
+constexpr int LDS_WBUF = 40 * 1024;
+constexpr int LDS_BIAS = 0;
+constexpr int LDS_W0 = 10 * 1024;
+constexpr int LDS_POSD = LDS_W0 + 2 * LDS_WBUF;               // [wave][cb][1 KiB]
+constexpr int LDS_POSX = LDS_POSD + WAVES * 2 * 1024;         // [wave][cb][2][1 KiB]
+constexpr int LDS_TOTAL = LDS_POSX + WAVES * 4 * 1024;
+static_assert(B16_BIAS_FLOATS * 4 <= LDS_W0, "bias table");
+static_assert(LDS_TOTAL <= 160 * 1024 && NUM_CHUNKS % 2 == 0, "LDS budget / parity");
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) void lds_void;
+template <class T>
+__device__ __forceinline__ T lds_load(unsigned base, int imm) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) T*>(
+        reinterpret_cast<lds_char*>(0) + base + imm);
+}
+template <class T>
+__device__ __forceinline__ void lds_store(unsigned base, int imm, const T& v) {
+    *reinterpret_cast<__attribute__((address_space(3))) T*>(
+        reinterpret_cast<lds_char*>(0) + base + imm) = v;
+}
+
+struct Ctx {
+    __amdgpu_buffer_rsrc_t wrsrc;
+    unsigned wave_goff, lane16;
+    unsigned b_wread[2];            // weight buffer p + lane*16
+    unsigned s_wdst[2];             // this wave's DMA piece in weight buffer p (wave-uniform)
+    unsigned b_bias;                // (lane>>4)*16
+    unsigned b_posx, b_posd;
+    int wave, lane;
+};
+
+struct State {
+    bf16x8 X[2][8], Y[2][8];        // [column block][k-step of 32]
+    f32x4 pend[2][2];               // [column block][tile of the pending pair]
+    float sigma[2], rgb[2][3];
+};
+
+template <bool RELU>
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const f32x2 v = {a, b};
+    const bf16x2 r = __builtin_convertvector(v, bf16x2);
+    if constexpr (RELU) {
+        const s16x2 z = {0, 0};
+        return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, r), z));
+    } else {
+        return __builtin_bit_cast(unsigned, r);
+    }
+}
+
+template <int CC>
+struct Stage {
+    static constexpr int NEXT = (CC + 1) % NUM_CHUNKS;
+    static constexpr int PIECES = (chunk_kib(NEXT) + WAVES - 1) / WAVES;
+    static constexpr int SRC_OFF = chunk_off_kib(NEXT) * 1024;
+    static __device__ __forceinline__ void issue(const Ctx& c) {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                c.wrsrc,
+                reinterpret_cast<lds_void*>(reinterpret_cast<lds_char*>(0) + c.s_wdst[NEXT & 1] + p * (WAVES * 1024)),
+                16, c.lane16, c.wave_goff + (SRC_OFF + p * WAVES * 1024), 0, 0);
+    }
+};
+
+// One of the 8 pieces of the epilogue of row-tile pair Q of layer L (tiles
+// 2Q, 2Q+1; both column blocks): piece i -> column block i>>2, word i&3 of the
+// next layer's fragment Q.  Heads: (L8, Q=8) is the lone sigma tile, L10 the
+// rgb tile.
+template <int L, int Q>
+__device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], bf16x8 (&dst)[2][8], State& st) {
+    constexpr LayerDesc D = layer_desc(L);
+    const int cb = i >> 2, j2 = i & 3;
+    if constexpr (L == 10) {
+        if (j2 == 0) { st.rgb[cb][0] = acc[cb][0][0]; st.rgb[cb][1] = acc[cb][0][1]; st.rgb[cb][2] = acc[cb][0][2]; }
+    } else if constexpr (L == 8 && Q == 8) {
+        if (j2 == 0) st.sigma[cb] = acc[cb][0][0];
+    } else {
+        u32x4 w = __builtin_bit_cast(u32x4, dst[cb][Q]);
+        w[j2] = pack2<D.relu != 0>(acc[cb][j2 >> 1][2 * (j2 & 1)], acc[cb][j2 >> 1][2 * (j2 & 1) + 1]);
+        dst[cb][Q] = __builtin_bit_cast(bf16x8, w);
+    }
+}
+
+// ---- one chunk: NT 16-row tiles of layer L starting at tile 4C -------------------
+// PL/PQ: layer / pair of the pending accumulators handed over by the previous chunk.
+template <int L, int C, int PL, int PQ>
+__device__ __forceinline__ void chunk_step(const Ctx& c, State& st, bf16x8 (&in)[2][8], bf16x8 (&out)[2][8]) {
+    constexpr LayerDesc D = layer_desc(L);
+    constexpr int KS_CHAIN = D.chain_k / 32;
+    constexpr int KS_EXTRA = D.extra_slots / 32;
+    constexpr int KS = KS_CHAIN + KS_EXTRA;
+    constexpr int CC = chunk_first(L) + C;
+    constexpr int NT = chunk_tiles(CC);
+    constexpr int RT0 = C * TPC;
+    constexpr int F = NT * KS;                      // weight fragments (each feeds 2 MFMAs)
+    constexpr int AHEAD = 4;
+    constexpr int BIAS_OFF = LDS_BIAS + (b16_bias_off(L) + 16 * RT0) * 4;
+    constexpr int XBLK = D.extra_kind == 1 ? 2048 : 1024;
+    // chunk-linear MFMA index m = (t*KS + ks)*2 + cb
+    constexpr int MT = 2 * KS;                      // MFMAs per row tile
+    constexpr int PEND_M0 = (L == 10) ? 0 : (NT * MT >= 12 ? 2 : 0);
+    constexpr int PEND_PER = (L == 10) ? 2 : 1;     // pieces per MFMA for the pending pair
+    constexpr int PAIR_M0 = 2 * MT + (MT >= 10 ? 2 : 0);
+    const unsigned wb = c.b_wread[CC & 1];
+    const unsigned xb = D.extra_kind == 1 ? c.b_posx : c.b_posd;
+
+    Stage<CC>::issue(c);
+
+    bf16x8 a[AHEAD];
+#pragma unroll
+    for (int f = 0; f < AHEAD && f < F; ++f) a[f] = lds_load<bf16x8>(wb, f * 1024);
+    bf16x8 bx[2][KS_EXTRA > 0 ? KS_EXTRA : 1];
+    if constexpr (KS_EXTRA > 0) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int e = 0; e < KS_EXTRA; ++e) bx[cb][e] = lds_load<bf16x8>(xb, cb * XBLK + e * 1024);
+    }
+    f32x4 acc[2][NT];
+    // register i of lane group g is row 16*rt + 4g + i: one 16-B bias read per tile
+    acc[0][0] = lds_load<f32x4>(c.b_bias, BIAS_OFF);
+    acc[1][0] = acc[0][0];
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int f = t * KS + ks;
+            const bf16x8 as = a[f % AHEAD];
+            if (f + AHEAD < F) a[f % AHEAD] = lds_load<bf16x8>(wb, (f + AHEAD) * 1024);
+            if (t + 1 < NT && ks == KS / 2) {
+                acc[0][t + 1 < NT ? t + 1 : 0] = lds_load<f32x4>(c.b_bias, BIAS_OFF + 64 * (t + 1));
+                acc[1][t + 1 < NT ? t + 1 : 0] = acc[0][t + 1 < NT ? t + 1 : 0];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int m = f * 2 + cb;
+                bf16x8 bs;
+                if (ks < KS_CHAIN) bs = in[cb][ks < KS_CHAIN ? ks : 0];
+                else bs = bx[cb][KS_EXTRA > 0 ? (ks - KS_CHAIN < KS_EXTRA ? ks - KS_CHAIN : 0) : 0];
+                acc[cb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as, bs, acc[cb][t], 0, 0, 0);
+                // ---- epilogue pieces in this MFMA's shadow
+                if constexpr (PL >= 0) {
+                    if (m >= PEND_M0 && m < PEND_M0 + 8 / PEND_PER) {
+#pragma unroll
+                        for (int k = 0; k < PEND_PER; ++k) {
+                            const int i = (m - PEND_M0) * PEND_PER + k;
+                            if constexpr (PL == L) epilogue_piece<PL, PQ>(i, st.pend, out, st);
+                            else epilogue_piece<PL, PQ>(i, st.pend, in, st);
+                        }
+                    }
+                }
+                if (NT == 4 && m >= PAIR_M0 && m < PAIR_M0 + 8) {
+                    const f32x4 pr[2][2] = {{acc[0][0], acc[0][NT > 1 ? 1 : 0]}, {acc[1][0], acc[1][NT > 1 ? 1 : 0]}};
+                    epilogue_piece<L, 2 * C>(m - PAIR_M0, pr, out, st);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        st.pend[cb][0] = acc[cb][NT >= 2 ? NT - 2 : 0];
+        st.pend[cb][1] = acc[cb][NT - 1];
+    }
+    __syncthreads();
+}
+
+__host__ __device__ constexpr int prev_layer(int L, int C) { return C > 0 ? L : L - 1; }
+__host__ __device__ constexpr int prev_pair(int L, int C) {
+    // pending pair when chunk (L, C) starts: same layer -> pair 2C-1; else the previous
+    // layer's last pair (L8 ends with its lone sigma tile, marked as pair 8)
+    return C > 0 ? 2 * C - 1 : (L > 0 ? (L - 1 == 8 ? 8 : b16_mt(L - 1) / 2 - 1) : 0);
+}
+
+template <int L, int... Cs>
+__device__ __forceinline__ void run_layer_seq(const Ctx& c, State& st, bf16x8 (&in)[2][8], bf16x8 (&out)[2][8],
+                                              std::integer_sequence<int, Cs...>) {
+    (chunk_step<L, Cs, prev_layer(L, Cs), prev_pair(L, Cs)>(c, st, in, out), ...);
+}
+template <int L>
+__device__ __forceinline__ void run_layer(const Ctx& c, State& st, bf16x8 (&in)[2][8], bf16x8 (&out)[2][8]) {
+    run_layer_seq<L>(c, st, in, out, std::make_integer_sequence<int, layer_chunks(L)>{});
+}
+
+// sin(2 pi (2^level q + trig/4)) with a per-lane level / trig
+__device__ __forceinline__ float enc_lane(TwoF q, int idx) {
+    const float sc = __builtin_amdgcn_ldexpf(1.0f, idx >> 1);
+    const float fr = __builtin_amdgcn_fractf(q.hi * sc) + q.lo * sc + ((idx & 1) ? 0.25f : 0.f);
+    return __builtin_amdgcn_sinf(fr);
+}
+
+template <bool RAYS>
+__device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base) {
+    const int col = c.lane & 15, g = c.lane >> 4;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        long long p = tile_base + c.wave * 32 + cb * 16 + col;
+        const bool valid = p < a.P;
+        if (!valid) p = a.P - 1;
+        PointIn pt;
+        if constexpr (RAYS) {
+            pt = fetch_point_rays(a, p);
+            if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
+        } else {
+            pt = fetch_point_pts(a, p);
+        }
+        {   // posx: 16 slots per lane group (nerf_layout::posx_col_f32)
+            const float xyz[3] = {pt.x, pt.y, pt.z};
+            float v[16];
+#pragma unroll
+            for (int cd = 0; cd < 3; ++cd) {
+                const TwoF q = to_revolutions(xyz[cd]);
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) v[cd * 5 + jj] = enc_lane(q, 5 * g + jj);
+            }
+            v[15] = g == 0 ? pt.x : g == 1 ? pt.y : g == 2 ? pt.z : 0.f;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                u32x4 r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) r[i] = pack2<false>(v[8 * e + 2 * i], v[8 * e + 2 * i + 1]);
+                lds_store<u32x4>(c.b_posx, cb * 2048 + e * 1024, r);
+            }
+        }
+        {   // posd: 8 slots per lane group (nerf_layout::posd_col_f32)
+            const float dd[3] = {pt.d1, pt.d2, pt.d3};
+            float v[8];
+#pragma unroll
+            for (int cd = 0; cd < 3; ++cd) {
+                const TwoF q = to_revolutions(dd[cd]);
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) v[cd * 2 + jj] = enc_lane(q, 2 * g + jj);
+            }
+            v[6] = g == 0 ? pt.d1 : g == 1 ? pt.d2 : g == 2 ? pt.d3 : 0.f;
+            v[7] = 0.f;
+            u32x4 r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) r[i] = pack2<false>(v[2 * i], v[2 * i + 1]);
+            lds_store<u32x4>(c.b_posd, cb * 1024, r);
+        }
+    }
+}
+
+template <bool RAYS>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bf16_16_kernel(MlpArgs a, long long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)smem;
+    Ctx c;
+    c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.lane = threadIdx.x & 63;
+    const char* img = reinterpret_cast<const char*>(a.packed) + B16_IMAGE_OFFSET;
+    c.wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), 0, (int)B16_IMAGE_BYTES, 0x00020000);
+    c.wave_goff = c.wave * 1024;
+    c.lane16 = c.lane * 16;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        c.b_wread[p] = LDS_W0 + p * LDS_WBUF + c.lane * 16;
+        c.s_wdst[p] = LDS_W0 + p * LDS_WBUF + c.wave * 1024;
+    }
+    c.b_bias = (c.lane >> 4) * 16;
+    c.b_posx = LDS_POSX + c.wave * 4096 + c.lane * 16;
+    c.b_posd = LDS_POSD + c.wave * 2048 + c.lane * 16;
+
+    {
+        const float* bsrc = reinterpret_cast<const float*>(img + (long long)B16_WEIGHT_KIB * 1024);
+        for (int i = threadIdx.x; i < B16_BIAS_FLOATS; i += WAVES * 64)
+            lds_store<float>(i * 4, LDS_BIAS, bsrc[i]);
+        Stage<NUM_CHUNKS - 1>::issue(c);
+    }
+    __syncthreads();
+
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long tile_base = tile * TILE_PTS;
+        asm volatile("" : "+s"(c.wave_goff));
+        stage_inputs<RAYS>(c, a, tile_base);
+
+        State st;
+        run_layer<0>(c, st, st.X, st.X);
+        run_layer<1>(c, st, st.X, st.Y);
+        run_layer<2>(c, st, st.Y, st.X);
+        run_layer<3>(c, st, st.X, st.Y);
+        run_layer<4>(c, st, st.Y, st.X);
+        run_layer<5>(c, st, st.X, st.Y);
+        run_layer<6>(c, st, st.Y, st.X);
+        run_layer<7>(c, st, st.X, st.Y);
+        run_layer<8>(c, st, st.Y, st.X);
+        run_layer<9>(c, st, st.X, st.Y);
+        run_layer<10>(c, st, st.Y, st.X);
+        epilogue_piece<10, 0>(0, st.pend, st.X, st);     // the rgb tile is still pending
+        epilogue_piece<10, 0>(4, st.pend, st.X, st);
+
+        if (c.lane < 16) {
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const long long p = tile_base + c.wave * 32 + cb * 16 + c.lane;
+                if (p < a.P) {
+                    const f32x4 o = {st.rgb[cb][0], st.rgb[cb][1], st.rgb[cb][2], st.sigma[cb]};
+                    *reinterpret_cast<f32x4*>(a.raw + p * 4) = o;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int nerf_amd_launch_mlp_bf16_16(const MlpArgs* args, int rays_mode, hipStream_t stream) {
+    (void)hipGetLastError();
+    MlpArgs a = *args;
+    if (a.P <= 0) return 0;
+    const long long ntiles = (a.P + TILE_PTS - 1) / TILE_PTS;
+    int dev = 0, cus = 256;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return (int)e;
+    const long long grid = ntiles < cus ? ntiles : cus;
+    auto kern = rays_mode ? nerf_mlp_bf16_16_kernel<true> : nerf_mlp_bf16_16_kernel<false>;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), LDS_TOTAL, stream, a, ntiles);
+    return (int)hipGetLastError();
+}

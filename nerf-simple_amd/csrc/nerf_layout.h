@@ -183,6 +183,43 @@ constexpr long long BF16_PACKED_BYTES = (long long)BF16_WEIGHT_KIB * 1024 + BIAS
 constexpr int BF16_MAX_CHUNK_KIB = 20;
 constexpr int NUM_CHUNKS = 8 * 8 + 9 + 4 + 1;                        // 78
 
+// ---- packed bf16 image, 16-row tiles (v_mfma_f32_16x16x32_bf16 variant) ----------
+// A wave's 64 lanes are 16 points x 4 lane groups g; a k-step covers 32 k's,
+// lane group g holding elements j = 0..7 (hardware k = 8g + j).  Two stacked
+// 16-row accumulator tiles (2q, 2q+1) give lane (c,g) rows 4g..4g+3 of each:
+// converted to bf16 they ARE the B fragment of the next layer's k-step q with
+NL_HD constexpr int chain_feat_b16(int q, int g, int j) {
+    return 32 * q + 16 * (j >> 2) + 4 * g + (j & 3);
+}
+// the extra (posx / posd) slots reuse the 4-lane-group maps of the f32 form
+NL_HD constexpr int src_col_b16(int L, int ks, int g, int j) {
+    const LayerDesc d = layer_desc(L);
+    const int chain_ks = d.chain_k / 32;
+    if (ks < chain_ks) return chain_feat_b16(ks, g, j);
+    const int t = 8 * (ks - chain_ks) + j;
+    const int c = d.extra_kind == 1 ? posx_col_f32(t, g) : posd_col_f32(t, g);
+    return c < 0 ? -1 : d.extra_col0 + c;
+}
+NL_HD constexpr int b16_mt(int L) { return L == 8 ? 17 : L == 10 ? 1 : layer_desc(L).mt * 2; }
+NL_HD constexpr int b16_ks(int L) { return layer_k(L) / 32; }       // 1 KiB fragments per 16-row tile
+NL_HD constexpr int b16_layer_off_kib(int L) {
+    int o = 0;
+    for (int i = 0; i < L; ++i) o += b16_mt(i) * b16_ks(i);
+    return o;
+}
+constexpr int B16_WEIGHT_KIB = b16_layer_off_kib(NUM_LAYERS);        // 1172
+NL_HD constexpr int b16_bias_off(int L) {
+    int o = 0;
+    for (int i = 0; i < L; ++i) o += b16_mt(i) * 16;
+    return o;
+}
+constexpr int B16_BIAS_FLOATS = b16_bias_off(NUM_LAYERS);            // 2464
+// the bf16 packed buffer holds both tilings back to back (the kernel variant is
+// chosen at launch): [32-row image | its bias | 16-row image | its bias]
+constexpr long long B16_IMAGE_OFFSET = ((long long)BF16_WEIGHT_KIB * 1024 + BIAS_FLOATS * 4 + 1023) / 1024 * 1024;
+constexpr long long B16_IMAGE_BYTES = (long long)B16_WEIGHT_KIB * 1024 + B16_BIAS_FLOATS * 4;
+constexpr long long BF16_PACKED_TOTAL_BYTES = B16_IMAGE_OFFSET + B16_IMAGE_BYTES;
+
 // ---- packed f32 image -----------------------------------------------------
 // 16-row output tiles (mfma_f32_16x16x4f32).  chunk = (layer, t): K/4 k-steps
 // x 64 lanes x 4 B, stored [ks/4][lane][4] so one ds_read_b128 per lane covers

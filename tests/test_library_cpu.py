@@ -40,7 +40,7 @@ def test_header_symbols_exported(lib):
 def test_introspection(lib):
     assert lib.nerf_amd_abi_version() == 1
     assert lib.nerf_amd_param_count() == 595844
-    assert lib.nerf_amd_packed_bytes(1) == 1192 * 1024 + 2496 * 4
+    assert lib.nerf_amd_packed_bytes(1) == 1202 * 1024 + 1172 * 1024 + 2464 * 4
     assert lib.nerf_amd_packed_bytes(0) == 2360 * 1024 + 154 * 16 * 4
     assert lib.nerf_amd_packed_bytes(7) < 0
     assert lib.nerf_amd_render_workspace_bytes(16000, 128) >= 16000 * 128 * 20
