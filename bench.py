@@ -97,8 +97,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rehearsal knobs (1-GPU box): NERF_BENCH_BACKEND=gloo NERF_BENCH_SHARE_GPU=1 lets
+        # several ranks share cuda:0; the driver's runs use the defaults (nccl = RCCL, one GPU per rank)
+        backend = os.environ.get("NERF_BENCH_BACKEND", "nccl")
+        if os.environ.get("NERF_BENCH_SHARE_GPU") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
