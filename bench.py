@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-rays", type=int, default=16000,
                     help="rays of the CPU-baseline sample (x128 samples; the reference's test batch)")
@@ -183,16 +183,17 @@ def main():
     if rank == 0:
         total_samples = n_rays * N_SAMPLES * args.steps
         value = total_samples / elapsed
-        peak = PEAK_BF16 if args.precision == "bf16" else PEAK_F32
+        peak = PEAK_F32 if args.precision == "fp32" else PEAK_BF16      # fp16 and bf16 MFMA rates are equal
         launch_samples = (hi - lo) * N_SAMPLES
         achieved = launch_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12
-        kern = "nerf_mlp_bf16_16_kernel<true>" if args.precision == "bf16" else "nerf_mlp_f32_kernel<true>"
+        kern = {"bf16": "nerf_mlp_bf16_16_kernel<true>", "fp16": "nerf_mlp_f16_16_kernel<true>",
+                "fp32": "nerf_mlp_f32_kernel<true>"}[args.precision]
         res = {
             "metric": "ray-samples/sec at 800x800x128", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "bf16" if args.precision == "bf16" else "f32", "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp16": "f16", "fp32": "f32"}[args.precision], "data": "synthetic",
             "config": {"workload": "lego-camera 800x800 single-view render, 128 samples/ray (BASELINE config 3)",
                        "rays": n_rays, "samples_per_ray": N_SAMPLES, "rays_per_launch": hi - lo,
                        "jitter": "device counter RNG", "weights": "synthetic_state_dict(0,'structured')",

@@ -36,7 +36,8 @@ extern "C" {
 
 /* precision of the fused MLP */
 #define NERF_AMD_F32   0   /* exact-f32 MFMA (v_mfma_f32_16x16x4_f32), fp32 end to end */
-#define NERF_AMD_BF16  1   /* bf16 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate */
+#define NERF_AMD_BF16  1   /* bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate (the flagship) */
+#define NERF_AMD_FP16  2   /* fp16 operands on v_mfma_f32_16x16x32_f16: same rate, 11-bit mantissa; range 65504 */
 
 /* flags of nerf_amd_render_forward / nerf_amd_mlp_forward_rays */
 #define NERF_AMD_TS_GIVEN   1u  /* `u` holds sample positions ts[B,N], not jitter */

@@ -18,10 +18,11 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP16 = 0, 1, 2
 FLAG_TS_GIVEN, FLAG_DEVICE_RNG = 1, 2
 _PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, F32: F32,
-               "bf16": BF16, "bfloat16": BF16, BF16: BF16}
+               "bf16": BF16, "bfloat16": BF16, BF16: BF16,
+               "fp16": FP16, "f16": FP16, "float16": FP16, "half": FP16, FP16: FP16}
 
 _lib = None
 _lock = threading.Lock()
@@ -61,7 +62,7 @@ def precision_code(p):
     try:
         return _PRECISIONS[p]
     except KeyError:
-        raise ValueError(f"precision must be 'fp32' or 'bf16', got {p!r}") from None
+        raise ValueError(f"precision must be 'fp32', 'bf16' or 'fp16', got {p!r}") from None
 
 
 def lib():

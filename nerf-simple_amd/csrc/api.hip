@@ -27,11 +27,12 @@ int nerf_amd_launch_sample_encode(const MlpArgs*, float*, float*, hipStream_t);
 int nerf_amd_launch_mlp_bf16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
+int nerf_amd_launch_mlp_f16_16(const MlpArgs*, int, hipStream_t);
 }
 
 namespace {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
-inline bool bad_precision(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16; }
+inline bool bad_precision(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16 && p != NERF_AMD_FP16; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 // bf16 has two MFMA-shape variants of the same kernel (32x32x16 and 16x16x32);
@@ -42,7 +43,8 @@ int bf16_tile() {
     return (e && e[0] == '3') ? 32 : (e && e[0] == '1') ? 16 : NERF_AMD_DEFAULT_BF16_TILE;
 }
 int launch_mlp(const MlpArgs& a, int rays_mode, int precision, hipStream_t s) {
-    if (precision != NERF_AMD_BF16) return nerf_amd_launch_mlp_f32(&a, rays_mode, s);
+    if (precision == NERF_AMD_F32) return nerf_amd_launch_mlp_f32(&a, rays_mode, s);
+    if (precision == NERF_AMD_FP16) return nerf_amd_launch_mlp_f16_16(&a, rays_mode, s);
     return bf16_tile() == 16 ? nerf_amd_launch_mlp_bf16_16(&a, rays_mode, s)
                              : nerf_amd_launch_mlp_bf16(&a, rays_mode, s);
 }
@@ -56,7 +58,8 @@ int64_t nerf_amd_param_count(void) { return PARAM_COUNT; }
 int64_t nerf_amd_packed_bytes(int precision) {
     if (bad_precision(precision)) return NERF_AMD_EINVAL;
     // + slack so that the staging loads of the last chunks stay inside the allocation
-    return (precision == NERF_AMD_BF16 ? BF16_PACKED_TOTAL_BYTES : F32_PACKED_BYTES);
+    return precision == NERF_AMD_BF16 ? BF16_PACKED_TOTAL_BYTES
+         : precision == NERF_AMD_FP16 ? B16_IMAGE_BYTES : F32_PACKED_BYTES;
 }
 
 int64_t nerf_amd_render_image_workspace_bytes(int64_t n_rays, int N) {

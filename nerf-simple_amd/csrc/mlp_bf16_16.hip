@@ -19,6 +19,24 @@
 
 using namespace nerf_layout;
 
+// The same source builds the bf16 kernel (default) and, with -DNERF_HALF, the
+// fp16 one (v_mfma_f32_16x16x32_f16: same rate, 11-bit mantissa instead of 8).
+#ifdef NERF_HALF
+typedef _Float16 elem_t;
+#define NERF_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define NERF_KERNEL nerf_mlp_f16_16_kernel
+#define NERF_LAUNCH nerf_amd_launch_mlp_f16_16
+static constexpr long long IMG_OFFSET = 0;                  // the fp16 packed buffer holds only this image
+#else
+typedef __bf16 elem_t;
+#define NERF_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define NERF_KERNEL nerf_mlp_bf16_16_kernel
+#define NERF_LAUNCH nerf_amd_launch_mlp_bf16_16
+static constexpr long long IMG_OFFSET = nerf_layout::B16_IMAGE_OFFSET;
+#endif
+typedef elem_t ex8 __attribute__((ext_vector_type(8)));
+typedef elem_t ex2 __attribute__((ext_vector_type(2)));
+
 namespace {
 
 constexpr int WAVES = 8;
@@ -81,7 +99,7 @@ struct Ctx {
 };
 
 struct State {
-    bf16x8 X[2][8], Y[2][8];        // [column block][k-step of 32]
+    ex8 X[2][8], Y[2][8];        // [column block][k-step of 32]
     f32x4 pend[2][2];               // [column block][tile of the pending pair]
     float sigma[2], rgb[2][3];
 };
@@ -89,7 +107,7 @@ struct State {
 template <bool RELU>
 __device__ __forceinline__ unsigned pack2(float a, float b) {
     const f32x2 v = {a, b};
-    const bf16x2 r = __builtin_convertvector(v, bf16x2);
+    const ex2 r = __builtin_convertvector(v, ex2);
     if constexpr (RELU) {
         const s16x2 z = {0, 0};
         return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, r), z));
@@ -118,7 +136,7 @@ struct Stage {
 // next layer's fragment Q.  Heads: (L8, Q=8) is the lone sigma tile, L10 the
 // rgb tile.
 template <int L, int Q>
-__device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], bf16x8 (&dst)[2][8], State& st) {
+__device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], ex8 (&dst)[2][8], State& st) {
     constexpr LayerDesc D = layer_desc(L);
     const int cb = i >> 2, j2 = i & 3;
     if constexpr (L == 10) {
@@ -128,14 +146,14 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
     } else {
         u32x4 w = __builtin_bit_cast(u32x4, dst[cb][Q]);
         w[j2] = pack2<D.relu != 0>(acc[cb][j2 >> 1][2 * (j2 & 1)], acc[cb][j2 >> 1][2 * (j2 & 1) + 1]);
-        dst[cb][Q] = __builtin_bit_cast(bf16x8, w);
+        dst[cb][Q] = __builtin_bit_cast(ex8, w);
     }
 }
 
 // ---- one chunk: NT 16-row tiles of layer L starting at tile 4C -------------------
 // PL/PQ: layer / pair of the pending accumulators handed over by the previous chunk.
 template <int L, int C, int PL, int PQ>
-__device__ __forceinline__ void chunk_step(const Ctx& c, State& st, bf16x8 (&in)[2][8], bf16x8 (&out)[2][8]) {
+__device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8]) {
     constexpr LayerDesc D = layer_desc(L);
     constexpr int KS_CHAIN = D.chain_k / 32;
     constexpr int KS_EXTRA = D.extra_slots / 32;
@@ -157,15 +175,15 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, bf16x8 (&in)
 
     Stage<CC>::issue(c);
 
-    bf16x8 a[AHEAD];
+    ex8 a[AHEAD];
 #pragma unroll
-    for (int f = 0; f < AHEAD && f < F; ++f) a[f] = lds_load<bf16x8>(wb, f * 1024);
-    bf16x8 bx[2][KS_EXTRA > 0 ? KS_EXTRA : 1];
+    for (int f = 0; f < AHEAD && f < F; ++f) a[f] = lds_load<ex8>(wb, f * 1024);
+    ex8 bx[2][KS_EXTRA > 0 ? KS_EXTRA : 1];
     if constexpr (KS_EXTRA > 0) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int e = 0; e < KS_EXTRA; ++e) bx[cb][e] = lds_load<bf16x8>(xb, cb * XBLK + e * 1024);
+            for (int e = 0; e < KS_EXTRA; ++e) bx[cb][e] = lds_load<ex8>(xb, cb * XBLK + e * 1024);
     }
     f32x4 acc[2][NT];
     // register i of lane group g is row 16*rt + 4g + i: one 16-B bias read per tile
@@ -178,8 +196,8 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, bf16x8 (&in)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int f = t * KS + ks;
-            const bf16x8 as = a[f % AHEAD];
-            if (f + AHEAD < F) a[f % AHEAD] = lds_load<bf16x8>(wb, (f + AHEAD) * 1024);
+            const ex8 as = a[f % AHEAD];
+            if (f + AHEAD < F) a[f % AHEAD] = lds_load<ex8>(wb, (f + AHEAD) * 1024);
             if (t + 1 < NT && ks == KS / 2) {
                 acc[0][t + 1 < NT ? t + 1 : 0] = lds_load<f32x4>(c.b_bias, BIAS_OFF + 64 * (t + 1));
                 acc[1][t + 1 < NT ? t + 1 : 0] = acc[0][t + 1 < NT ? t + 1 : 0];
@@ -188,10 +206,10 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, bf16x8 (&in)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb) {
                 const int m = f * 2 + cb;
-                bf16x8 bs;
+                ex8 bs;
                 if (ks < KS_CHAIN) bs = in[cb][ks < KS_CHAIN ? ks : 0];
                 else bs = bx[cb][KS_EXTRA > 0 ? (ks - KS_CHAIN < KS_EXTRA ? ks - KS_CHAIN : 0) : 0];
-                acc[cb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as, bs, acc[cb][t], 0, 0, 0);
+                acc[cb][t] = NERF_MFMA(as, bs, acc[cb][t], 0, 0, 0);
                 // ---- epilogue pieces in this MFMA's shadow
                 if constexpr (PL >= 0) {
                     if (m >= PEND_M0 && m < PEND_M0 + 8 / PEND_PER) {
@@ -227,12 +245,12 @@ __host__ __device__ constexpr int prev_pair(int L, int C) {
 }
 
 template <int L, int... Cs>
-__device__ __forceinline__ void run_layer_seq(const Ctx& c, State& st, bf16x8 (&in)[2][8], bf16x8 (&out)[2][8],
+__device__ __forceinline__ void run_layer_seq(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8],
                                               std::integer_sequence<int, Cs...>) {
     (chunk_step<L, Cs, prev_layer(L, Cs), prev_pair(L, Cs)>(c, st, in, out), ...);
 }
 template <int L>
-__device__ __forceinline__ void run_layer(const Ctx& c, State& st, bf16x8 (&in)[2][8], bf16x8 (&out)[2][8]) {
+__device__ __forceinline__ void run_layer(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8]) {
     run_layer_seq<L>(c, st, in, out, std::make_integer_sequence<int, layer_chunks(L)>{});
 }
 
@@ -296,13 +314,13 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
 }
 
 template <bool RAYS>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bf16_16_kernel(MlpArgs a, long long ntiles) {
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, long long ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     (void)smem;
     Ctx c;
     c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.lane = threadIdx.x & 63;
-    const char* img = reinterpret_cast<const char*>(a.packed) + B16_IMAGE_OFFSET;
+    const char* img = reinterpret_cast<const char*>(a.packed) + IMG_OFFSET;
     c.wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), 0, (int)B16_IMAGE_BYTES, 0x00020000);
     c.wave_goff = c.wave * 1024;
     c.lane16 = c.lane * 16;
@@ -358,7 +376,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bf16_16_kernel
 
 }  // namespace
 
-extern "C" int nerf_amd_launch_mlp_bf16_16(const MlpArgs* args, int rays_mode, hipStream_t stream) {
+extern "C" int NERF_LAUNCH(const MlpArgs* args, int rays_mode, hipStream_t stream) {
     (void)hipGetLastError();
     MlpArgs a = *args;
     if (a.P <= 0) return 0;
@@ -369,7 +387,7 @@ extern "C" int nerf_amd_launch_mlp_bf16_16(const MlpArgs* args, int rays_mode, h
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return (int)e;
     const long long grid = ntiles < cus ? ntiles : cus;
-    auto kern = rays_mode ? nerf_mlp_bf16_16_kernel<true> : nerf_mlp_bf16_16_kernel<false>;
+    auto kern = rays_mode ? NERF_KERNEL<true> : NERF_KERNEL<false>;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) return (int)e;

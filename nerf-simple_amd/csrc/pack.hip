@@ -29,7 +29,8 @@ __global__ void pack_bf16_kernel(const float* __restrict__ params, __bf16* __res
 }
 
 // bf16 image, 16-row tiles: [tile (layer, rt)][k-step][lane][8 bf16]
-__global__ void pack_b16_kernel(const float* __restrict__ params, __bf16* __restrict__ out) {
+template <class T>
+__global__ void pack_b16_kernel(const float* __restrict__ params, T* __restrict__ out) {
     const long long total = (long long)B16_WEIGHT_KIB * 512;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {
@@ -40,7 +41,7 @@ __global__ void pack_b16_kernel(const float* __restrict__ params, __bf16* __rest
         const int rt = rel / b16_ks(L), s = rel % b16_ks(L);
         const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
         const int row = 16 * rt + (lane & 15), g = lane >> 4;
-        out[e] = (__bf16)weight_at(params, L, row, src_col_b16(L, s, g, j));
+        out[e] = (T)weight_at(params, L, row, src_col_b16(L, s, g, j));
     }
 }
 
@@ -91,11 +92,17 @@ extern "C" int nerf_amd_launch_pack(const float* params, void* packed, int preci
         float* bias = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + (long long)BF16_WEIGHT_KIB * 1024);
         hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params, bias, 0);
         char* img16 = reinterpret_cast<char*>(packed) + B16_IMAGE_OFFSET;
-        hipLaunchKernelGGL(pack_b16_kernel, dim3(1024), dim3(256), 0, stream, params,
+        hipLaunchKernelGGL(pack_b16_kernel<__bf16>, dim3(1024), dim3(256), 0, stream, params,
                            reinterpret_cast<__bf16*>(img16));
         // 16-row bias table == the f32 path's (natural row order, 16 per tile)
         hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params,
                            reinterpret_cast<float*>(img16 + (long long)B16_WEIGHT_KIB * 1024), 1);
+    } else if (precision == 2) {
+        // fp16: the 16-row image only, at offset 0
+        hipLaunchKernelGGL(pack_b16_kernel<_Float16>, dim3(1024), dim3(256), 0, stream, params,
+                           reinterpret_cast<_Float16*>(packed));
+        hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params,
+                           reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + (long long)B16_WEIGHT_KIB * 1024), 1);
     } else {
         hipLaunchKernelGGL(pack_f32_kernel, dim3(1024), dim3(256), 0, stream, params,
                            reinterpret_cast<float*>(packed));

@@ -91,7 +91,8 @@ def volume_render_autograd(nerf_outs, ts, dirs):
 def _dense_layers(net, x, d, precision):
     """Data-flow of reference utils/nets.py:37-43 on already-encoded inputs,
     through the module's own nn.Linear parameters so autograd reaches them."""
-    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(_lib.precision_code(precision) == _lib.BF16)):
+    # 16-bit modes run the library GEMMs under bf16 autocast (fp16 would need loss scaling)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(_lib.precision_code(precision) != _lib.F32)):
         h = net.layers_0(x)
         h = net.skip_conn_layer(torch.cat([h, x.to(h.dtype)], dim=1))
         h = net.layers_1(h)

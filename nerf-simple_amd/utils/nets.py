@@ -24,9 +24,10 @@ class Nerf(nn.Module):
     forward(v): v [P,6] = [x,y,z,d1,d2,d3] -> [P,4] = [r,g,b,sigma], raw (no
     sigmoid on rgb; softplus on sigma is applied by the compositor).
 
-    precision: 'bf16' (bf16 MFMA operands, fp32 accumulate; default) or
-               'fp32' (exact-f32 MFMA).  Keyword-only superset of the
-               reference signature.
+    precision: 'bf16' (bf16 MFMA operands, fp32 accumulate; default),
+               'fp16' (fp16 operands: same MFMA rate, 8x finer mantissa, values
+               must stay below 65504) or 'fp32' (exact-f32 MFMA).  Keyword-only
+               superset of the reference signature.
     """
 
     def __init__(self, Lp=10, Ld=4, H=256, *, precision=None):

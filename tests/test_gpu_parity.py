@@ -11,6 +11,8 @@ Tolerances (stated once, used below):
   BF16_*     bf16 operands (8-bit mantissa) with fp32 accumulation: ~3e-3
              relative per layer, bound 4e-2 of the output scale; the image-level
              criterion is PSNR (test_image_psnr).
+  FP16_TOL   fp16 operands (11-bit mantissa): 8x tighter than bf16; observed ~2e-3
+             on the structured weights.
   CMP_RTOL   compositor alone: identical formulas, scan order differs from
              torch.cumprod's sequential order by a few ulp.
 """
@@ -23,6 +25,7 @@ pytestmark = pytest.mark.gpu
 ENC_ATOL = 5e-7
 F32_TOL = 1e-4
 BF16_TOL = 4e-2
+FP16_TOL = 5e-3           # 11-bit mantissa: 8x below bf16
 CMP_RTOL = 2e-5
 CMP_ATOL = 1e-6
 NAMES = ("rgb", "disp", "alpha", "acc", "w")
@@ -87,7 +90,7 @@ def test_encode_empty_and_other_levels(dev, oracle):
 
 # ---------------------------------------------------------------- the MLP
 @pytest.mark.parametrize("kind", ["default", "structured"])
-@pytest.mark.parametrize("precision,tol", [("fp32", F32_TOL), ("bf16", BF16_TOL)])
+@pytest.mark.parametrize("precision,tol", [("fp32", F32_TOL), ("bf16", BF16_TOL), ("fp16", FP16_TOL)])
 def test_mlp_golden(dev, golden, synthetic, kind, precision, tol):
     g = golden(f"mlp_{kind}.npz")
     net = make_net(synthetic, dev, kind, precision)
@@ -107,7 +110,7 @@ def test_mlp_ragged_sizes(dev, oracle, synthetic, P):
     v = synthetic.points_in_scene(P, seed=P)
     with torch.no_grad():
         want = oracle.nerf_forward(sd, v).numpy()
-    for precision, tol in (("fp32", F32_TOL), ("bf16", BF16_TOL)):
+    for precision, tol in (("fp32", F32_TOL), ("bf16", BF16_TOL), ("fp16", FP16_TOL)):
         net = make_net(synthetic, dev, "structured", precision)
         guard = torch.full((P + 64, 4), 777.0, device=dev)
         with torch.no_grad():
@@ -183,7 +186,7 @@ def test_composite_odd_sizes(dev, oracle):
 
 # ---------------------------------------------------------------- render_nerf
 @pytest.mark.parametrize("kind", ["default", "structured"])
-@pytest.mark.parametrize("precision,tol", [("fp32", F32_TOL), ("bf16", BF16_TOL)])
+@pytest.mark.parametrize("precision,tol", [("fp32", F32_TOL), ("bf16", BF16_TOL), ("fp16", FP16_TOL)])
 def test_render_golden(dev, golden, synthetic, kind, precision, tol):
     from nerf_simple_amd.utils.rendering import render_nerf, render_rays
     assert render_rays is render_nerf
@@ -307,11 +310,13 @@ def test_image_golden_fp32(dev, golden, synthetic, kind):
 
 
 # (kind, precision) -> (max |PSNR(GPU,T) - PSNR(CPU,T)| dB, min PSNR(GPU,CPU) dB)
-# BASELINE's criterion is 0.05 dB.  bf16 meets it at trained-model-like weight
+# BASELINE's criterion is 0.05 dB.  fp16 (same MFMA rate) and fp32 meet it on both weight
+# sets; bf16 meets it at trained-model-like weight
 # scale ("default") and misses it on the "structured" stress set, whose head
 # gains (sigma x8) amplify the 8-bit-mantissa rounding of weights and
 # activations ~10x (DESIGN.md section 6 quantifies the sources).
 PSNR_BOUNDS = {("default", "bf16"): (0.05, 55.0), ("structured", "bf16"): (0.30, 45.0),
+               ("default", "fp16"): (0.05, 75.0), ("structured", "fp16"): (0.05, 58.0),
                ("default", "fp32"): (0.01, 90.0), ("structured", "fp32"): (0.01, 80.0)}
 
 
