@@ -37,6 +37,7 @@ extern "C" {
 /* precision of the fused MLP */
 #define NERF_AMD_F32   0   /* exact-f32 MFMA (v_mfma_f32_16x16x4_f32), fp32 end to end */
 #define NERF_AMD_BF16  1   /* bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate (the flagship) */
+#define NERF_AMD_BF16_BWD 3 /* nerf_amd_pack_weights / nerf_amd_packed_bytes only: the transposed image of nerf_amd_mlp_backward */
 #define NERF_AMD_FP16  2   /* fp16 operands on v_mfma_f32_16x16x32_f16: same rate, 11-bit mantissa; range 65504 */
 
 /* flags of nerf_amd_render_forward / nerf_amd_mlp_forward_rays */
@@ -169,6 +170,23 @@ int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u,
 int nerf_amd_sample_encode(const float* rays, const float* u, const float* tbins,
                            uint32_t flags, uint64_t seed, int64_t ray_id0,
                            float* posx, float* posd, float* ts, int64_t B, int N, void* stream);
+
+/* ---- fused training path of the dense layers (reference train.py:51-54) --------
+ * Forward as nerf_amd_mlp_forward_rays (bf16) that ALSO saves every layer's output
+ * (bf16, row-major, layer L at byte offset L*P*512: L0..L7 post-ReLU [P,256], L8 = the
+ * linear 256->256 [P,256], L9 = colour hidden [P,128]; P = B*N) for the backward. */
+int64_t nerf_amd_train_activation_bytes(int64_t P);
+int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* tbins,
+                               const void* packed_bf16, uint32_t flags, uint64_t seed, int64_t ray_id0,
+                               float* raw, float* ts, void* acts, int64_t B, int N, void* stream);
+/* Backward dX chain: d_raw[P,4] (from nerf_amd_volume_render_backward) + the saved
+ * activations (their zeros are the ReLU masks) -> dys: every layer's
+ * pre-activation gradient, bf16 row-major, same layout as `acts`.  The gradient
+ * w.r.t. activations stays on-chip between layers.  `bwd_image` from
+ * nerf_amd_pack_weights(..., NERF_AMD_BF16_BWD).  Weight gradients are then
+ * dW_L = dys[L]^T @ input_L: plain GEMMs over P, left to the BLAS library. */
+int nerf_amd_mlp_backward(const float* d_raw, const void* bwd_image, const void* acts,
+                          void* dys, int64_t P, void* stream);
 
 #ifdef __cplusplus
 }

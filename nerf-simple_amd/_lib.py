@@ -18,11 +18,12 @@ import torch  # noqa: F401
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
 
-F32, BF16, FP16 = 0, 1, 2
+F32, BF16, FP16, BF16_BWD = 0, 1, 2, 3
 FLAG_TS_GIVEN, FLAG_DEVICE_RNG = 1, 2
 _PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, F32: F32,
                "bf16": BF16, "bfloat16": BF16, BF16: BF16,
-               "fp16": FP16, "f16": FP16, "float16": FP16, "half": FP16, FP16: FP16}
+               "fp16": FP16, "f16": FP16, "float16": FP16, "half": FP16, FP16: FP16,
+               "bf16_bwd": BF16_BWD, BF16_BWD: BF16_BWD}     # the backward kernel's transposed image
 
 _lib = None
 _lock = threading.Lock()
@@ -50,6 +51,9 @@ _SIGNATURES = {
     "nerf_amd_render_image_forward": (_i32, [_vp, _i32, _i32, ctypes.c_float, _i64, _i64, _vp, _vp, _vp, _i32,
                                              _u32, _u64, _vp, _vp, _i32, _vp]),
     "nerf_amd_sample_pdf": (_i32, [_vp, _vp, _vp, _u32, _u64, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "nerf_amd_train_activation_bytes": (_i64, [_i64]),
+    "nerf_amd_mlp_forward_train": (_i32, [_vp, _vp, _vp, _vp, _u32, _u64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_mlp_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "nerf_amd_render_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _u32, _u64, _i64,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_mlp_forward_rays": (_i32, [_vp, _vp, _vp, _vp, _i32, _u32, _u64, _i64,

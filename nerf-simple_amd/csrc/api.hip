@@ -28,11 +28,13 @@ int nerf_amd_launch_mlp_bf16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f16_16(const MlpArgs*, int, hipStream_t);
+int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, long long, hipStream_t);
 }
 
 namespace {
 inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool bad_precision(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16 && p != NERF_AMD_FP16; }
+inline bool bad_image(int p) { return bad_precision(p) && p != NERF_AMD_BF16_BWD; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
 // bf16 has two MFMA-shape variants of the same kernel (32x32x16 and 16x16x32);
@@ -56,7 +58,8 @@ int nerf_amd_abi_version(void) { return NERF_AMD_ABI_VERSION; }
 int64_t nerf_amd_param_count(void) { return PARAM_COUNT; }
 
 int64_t nerf_amd_packed_bytes(int precision) {
-    if (bad_precision(precision)) return NERF_AMD_EINVAL;
+    if (bad_image(precision)) return NERF_AMD_EINVAL;
+    if (precision == NERF_AMD_BF16_BWD) return BWD_IMAGE_BYTES;
     // + slack so that the staging loads of the last chunks stay inside the allocation
     return precision == NERF_AMD_BF16 ? BF16_PACKED_TOTAL_BYTES
          : precision == NERF_AMD_FP16 ? B16_IMAGE_BYTES : F32_PACKED_BYTES;
@@ -142,7 +145,7 @@ int nerf_amd_layout_selfcheck(void) {
 }
 
 int nerf_amd_pack_weights(const float* params, void* packed, int precision, void* stream) {
-    if (!params || !packed || bad_precision(precision)) return NERF_AMD_EINVAL;
+    if (!params || !packed || bad_image(precision)) return NERF_AMD_EINVAL;
     return nerf_amd_launch_pack(params, packed, precision, S(stream));
 }
 
@@ -283,6 +286,32 @@ int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u, uint32_
     if (!(flags & NERF_AMD_DEVICE_RNG) && !u && Nf > 0) return NERF_AMD_EINVAL;
     return nerf_amd_launch_sample_pdf(ts, w, u, ts_out, B, Nc, Nf, seed, ray_id0,
                                       (flags & NERF_AMD_DEVICE_RNG) ? 1 : 0, S(stream));
+}
+
+int64_t nerf_amd_train_activation_bytes(int64_t P) {
+    return P < 0 ? (int64_t)NERF_AMD_EINVAL : (int64_t)acts_total_bytes(P);
+}
+
+int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* tbins, const void* packed,
+                               uint32_t flags, uint64_t seed, int64_t ray_id0, float* raw, float* ts,
+                               void* acts, int64_t B, int N, void* stream) {
+    if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (!rays || !packed || !raw || !acts) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+    MlpArgs a{};
+    a.rays = rays; a.u = u; a.tbins = tbins; a.packed = packed; a.raw = raw; a.ts_out = ts; a.acts = acts;
+    a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
+    return nerf_amd_launch_mlp_bf16_16(&a, 1, S(stream));
+}
+
+int nerf_amd_mlp_backward(const float* d_raw, const void* bwd_image, const void* acts, void* dys, int64_t P,
+                          void* stream) {
+    if (P < 0) return NERF_AMD_EINVAL;
+    if (P == 0) return 0;
+    if (!d_raw || !bwd_image || !acts || !dys) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_mlp_backward(d_raw, bwd_image, acts, dys, P, S(stream));
 }
 
 }  // extern "C"

@@ -102,6 +102,11 @@ struct State {
     ex8 X[2][8], Y[2][8];        // [column block][k-step of 32]
     f32x4 pend[2][2];               // [column block][tile of the pending pair]
     float sigma[2], rgb[2][3];
+    // training forward only (SAVE): where this lane's activations go
+    char* acts;
+    long long P;
+    long long prow[2];              // point index of column block cb, -1 past the end
+    int goff;                       // (lane>>4) * 8 bytes
 };
 
 template <bool RELU>
@@ -135,7 +140,7 @@ struct Stage {
 // 2Q, 2Q+1; both column blocks): piece i -> column block i>>2, word i&3 of the
 // next layer's fragment Q.  Heads: (L8, Q=8) is the lone sigma tile, L10 the
 // rgb tile.
-template <int L, int Q>
+template <int L, int Q, bool SAVE = false>
 __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], ex8 (&dst)[2][8], State& st) {
     constexpr LayerDesc D = layer_desc(L);
     const int cb = i >> 2, j2 = i & 3;
@@ -147,12 +152,21 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
         u32x4 w = __builtin_bit_cast(u32x4, dst[cb][Q]);
         w[j2] = pack2<D.relu != 0>(acc[cb][j2 >> 1][2 * (j2 & 1)], acc[cb][j2 >> 1][2 * (j2 & 1) + 1]);
         dst[cb][Q] = __builtin_bit_cast(ex8, w);
+        if constexpr (SAVE) {
+            // the fragment is complete: write this lane's 2 x 4 features of layer L's output
+            // (row-major [P, width] bf16; features 32Q+4g.. and 32Q+16+4g..) for the backward pass
+            if (j2 == 3 && st.prow[cb] >= 0) {
+                char* rp = st.acts + act_offset_bytes(L, st.P) + st.prow[cb] * (act_width(L) * 2) + 64 * Q + st.goff;
+                *reinterpret_cast<f32x2*>(rp) = __builtin_bit_cast(f32x2, __builtin_shufflevector(w, w, 0, 1));
+                *reinterpret_cast<f32x2*>(rp + 32) = __builtin_bit_cast(f32x2, __builtin_shufflevector(w, w, 2, 3));
+            }
+        }
     }
 }
 
 // ---- one chunk: NT 16-row tiles of layer L starting at tile 4C -------------------
 // PL/PQ: layer / pair of the pending accumulators handed over by the previous chunk.
-template <int L, int C, int PL, int PQ>
+template <int L, int C, int PL, int PQ, bool SAVE>
 __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8]) {
     constexpr LayerDesc D = layer_desc(L);
     constexpr int KS_CHAIN = D.chain_k / 32;
@@ -170,6 +184,9 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
     constexpr int PEND_M0 = (L == 10) ? 0 : (NT * MT >= 12 ? 2 : 0);
     constexpr int PEND_PER = (L == 10) ? 2 : 1;     // pieces per MFMA for the pending pair
     constexpr int PAIR_M0 = 2 * MT + (MT >= 10 ? 2 : 0);
+    // a pending pair of the PREVIOUS layer is this layer's k-step PQ, first read by MFMA 2*PQ
+    static_assert(PL < 0 || PL == L || (PL == 8 && PQ == 8) || 2 * PQ >= PEND_M0 + 8 / PEND_PER,
+                  "pending pair finished too late");
     const unsigned wb = c.b_wread[CC & 1];
     const unsigned xb = D.extra_kind == 1 ? c.b_posx : c.b_posd;
 
@@ -216,14 +233,14 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
 #pragma unroll
                         for (int k = 0; k < PEND_PER; ++k) {
                             const int i = (m - PEND_M0) * PEND_PER + k;
-                            if constexpr (PL == L) epilogue_piece<PL, PQ>(i, st.pend, out, st);
-                            else epilogue_piece<PL, PQ>(i, st.pend, in, st);
+                            if constexpr (PL == L) epilogue_piece<PL, PQ, SAVE>(i, st.pend, out, st);
+                            else epilogue_piece<PL, PQ, SAVE>(i, st.pend, in, st);
                         }
                     }
                 }
                 if (NT == 4 && m >= PAIR_M0 && m < PAIR_M0 + 8) {
                     const f32x4 pr[2][2] = {{acc[0][0], acc[0][NT > 1 ? 1 : 0]}, {acc[1][0], acc[1][NT > 1 ? 1 : 0]}};
-                    epilogue_piece<L, 2 * C>(m - PAIR_M0, pr, out, st);
+                    epilogue_piece<L, 2 * C, SAVE>(m - PAIR_M0, pr, out, st);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -244,14 +261,14 @@ __host__ __device__ constexpr int prev_pair(int L, int C) {
     return C > 0 ? 2 * C - 1 : (L > 0 ? (L - 1 == 8 ? 8 : b16_mt(L - 1) / 2 - 1) : 0);
 }
 
-template <int L, int... Cs>
+template <int L, bool SAVE, int... Cs>
 __device__ __forceinline__ void run_layer_seq(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8],
                                               std::integer_sequence<int, Cs...>) {
-    (chunk_step<L, Cs, prev_layer(L, Cs), prev_pair(L, Cs)>(c, st, in, out), ...);
+    (chunk_step<L, Cs, prev_layer(L, Cs), prev_pair(L, Cs), SAVE>(c, st, in, out), ...);
 }
-template <int L>
+template <int L, bool SAVE>
 __device__ __forceinline__ void run_layer(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8]) {
-    run_layer_seq<L>(c, st, in, out, std::make_integer_sequence<int, layer_chunks(L)>{});
+    run_layer_seq<L, SAVE>(c, st, in, out, std::make_integer_sequence<int, layer_chunks(L)>{});
 }
 
 // sin(2 pi (2^level q + trig/4)) with a per-lane level / trig
@@ -262,12 +279,13 @@ __device__ __forceinline__ float enc_lane(TwoF q, int idx) {
 }
 
 template <bool RAYS>
-__device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base) {
+__device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base, State& st) {
     const int col = c.lane & 15, g = c.lane >> 4;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         long long p = tile_base + c.wave * 32 + cb * 16 + col;
         const bool valid = p < a.P;
+        st.prow[cb] = valid ? p : -1;
         if (!valid) p = a.P - 1;
         PointIn pt;
         if constexpr (RAYS) {
@@ -313,7 +331,7 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
     }
 }
 
-template <bool RAYS>
+template <bool RAYS, bool SAVE>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, long long ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     (void)smem;
@@ -344,20 +362,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long long tile_base = tile * TILE_PTS;
         asm volatile("" : "+s"(c.wave_goff));
-        stage_inputs<RAYS>(c, a, tile_base);
-
         State st;
-        run_layer<0>(c, st, st.X, st.X);
-        run_layer<1>(c, st, st.X, st.Y);
-        run_layer<2>(c, st, st.Y, st.X);
-        run_layer<3>(c, st, st.X, st.Y);
-        run_layer<4>(c, st, st.Y, st.X);
-        run_layer<5>(c, st, st.X, st.Y);
-        run_layer<6>(c, st, st.Y, st.X);
-        run_layer<7>(c, st, st.X, st.Y);
-        run_layer<8>(c, st, st.Y, st.X);
-        run_layer<9>(c, st, st.X, st.Y);
-        run_layer<10>(c, st, st.Y, st.X);
+        st.acts = reinterpret_cast<char*>(a.acts);
+        st.P = a.P;
+        st.goff = (c.lane >> 4) * 8;
+        stage_inputs<RAYS>(c, a, tile_base, st);
+
+        run_layer<0, SAVE>(c, st, st.X, st.X);
+        run_layer<1, SAVE>(c, st, st.X, st.Y);
+        run_layer<2, SAVE>(c, st, st.Y, st.X);
+        run_layer<3, SAVE>(c, st, st.X, st.Y);
+        run_layer<4, SAVE>(c, st, st.Y, st.X);
+        run_layer<5, SAVE>(c, st, st.X, st.Y);
+        run_layer<6, SAVE>(c, st, st.Y, st.X);
+        run_layer<7, SAVE>(c, st, st.X, st.Y);
+        run_layer<8, SAVE>(c, st, st.Y, st.X);
+        run_layer<9, SAVE>(c, st, st.X, st.Y);
+        run_layer<10, SAVE>(c, st, st.Y, st.X);
         epilogue_piece<10, 0>(0, st.pend, st.X, st);     // the rgb tile is still pending
         epilogue_piece<10, 0>(4, st.pend, st.X, st);
 
@@ -387,7 +408,14 @@ extern "C" int NERF_LAUNCH(const MlpArgs* args, int rays_mode, hipStream_t strea
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return (int)e;
     const long long grid = ntiles < cus ? ntiles : cus;
-    auto kern = rays_mode ? NERF_KERNEL<true> : NERF_KERNEL<false>;
+#ifdef NERF_HALF
+    if (a.acts) return -2;                       // the training forward exists in bf16 only
+    auto kern = rays_mode ? NERF_KERNEL<true, false> : NERF_KERNEL<false, false>;
+#else
+    if (a.acts && !rays_mode) return -2;
+    auto kern = a.acts ? NERF_KERNEL<true, true>
+                       : (rays_mode ? NERF_KERNEL<true, false> : NERF_KERNEL<false, false>);
+#endif
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e != hipSuccess) return (int)e;

@@ -1,0 +1,324 @@
+// mlp_bwd_16.hip -- training backward of the 12 dense layers, dX chain.
+//
+// Autograd through Nerf.forward (reference utils/nets.py:34-43) inside the
+// training step (reference train.py:51-54), restricted to what the step needs:
+// gradients w.r.t. the PARAMETERS.  This kernel computes, for a tile of 256
+// points, every layer's pre-activation gradient dY_l = relu'(h_l) (.) (W_{l+1}^T
+// dY_{l+1}) with the same on-chip chaining as the forward kernel
+// (mlp_bf16_16.hip; read its header first): the accumulators of one backward
+// layer, masked and converted to bf16, are the B operand of the next one, so the
+// gradient w.r.t. activations never leaves the CU.  It reads d_raw[P,4] (from
+// the compositor's backward) and the ReLU masks (the forward's saved bf16
+// activations, non-zero <=> active) and writes dY_l [P, width] bf16 row-major.
+// The weight gradients dW_l = dY_l^T X_l are plain GEMMs over the point
+// dimension and run in the vendor library (training.py).
+//
+// 10 backward layers (nerf_layout::bwd_desc), 38 weight chunks per tile streamed
+// L2 -> LDS by LDS-DMA exactly as in the forward.  HBM-bound by construction:
+// ~5 KB of masks read and ~5 KB of dY written per point.
+#include "nerf_device.h"
+#include <utility>
+
+using namespace nerf_layout;
+
+typedef __bf16 ex8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ex2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct BwdArgs {
+    const float* d_raw;       // [P,4] = d loss / d [r,g,b,sigma]
+    const void* image;        // backward weight image (nerf_amd_pack_weights precision 3)
+    const char* acts;         // saved forward activations
+    char* dys;                // out: pre-activation gradients, same layout as acts
+    long long P;
+};
+
+namespace {
+
+constexpr int WAVES = 8;
+constexpr int TILE_PTS = WAVES * 32;
+constexpr int TPC = 4;
+
+__host__ __device__ constexpr int layer_chunks(int b) { return (bwd_mt(b) + TPC - 1) / TPC; }
+__host__ __device__ constexpr int chunk_first(int b) {
+    int c = 0;
+    for (int i = 0; i < b; ++i) c += layer_chunks(i);
+    return c;
+}
+constexpr int NUM_CHUNKS = chunk_first(NUM_BWD);              // 38
+__host__ __device__ constexpr int chunk_layer(int cc) {
+    int b = 0;
+    while (cc >= layer_chunks(b)) { cc -= layer_chunks(b); ++b; }
+    return b;
+}
+__host__ __device__ constexpr int chunk_kib(int cc) { return TPC * bwd_ks(chunk_layer(cc)); }
+__host__ __device__ constexpr int chunk_off_kib(int cc) {
+    const int b = chunk_layer(cc), C = cc - chunk_first(b);
+    return bwd_layer_off_kib(b) + C * TPC * bwd_ks(b);
+}
+
+constexpr int LDS_WBUF = 40 * 1024;
+constexpr int LDS_W0 = 0;
+constexpr int LDS_TOTAL = 2 * LDS_WBUF;
+static_assert(NUM_CHUNKS % 2 == 0, "buffer parity must repeat per tile");
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) void lds_void;
+template <class T>
+__device__ __forceinline__ T lds_load(unsigned base, int imm) {
+    return *reinterpret_cast<const __attribute__((address_space(3))) T*>(
+        reinterpret_cast<lds_char*>(0) + base + imm);
+}
+
+struct Ctx {
+    __amdgpu_buffer_rsrc_t wrsrc;
+    unsigned wave_goff, lane16;
+    unsigned b_wread[2], s_wdst[2];
+    int wave, lane;
+};
+
+struct State {
+    ex8 X[2][8], Y[2][8];           // dY fragments, ping-pong
+    f32x4 pend[2][2];               // pending pair accumulators [cb][tile]
+    u32x2 pmask[2][2];              // its ReLU-mask halves [cb][half]
+    ex8 bx_rgb[2], bx_sig[2];       // custom k-steps built from d_raw
+    const char* acts;
+    char* dys;
+    long long P, prow[2];
+    int goff;
+};
+
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ex2));
+}
+
+template <int CC>
+struct Stage {
+    static constexpr int NEXT = (CC + 1) % NUM_CHUNKS;
+    static constexpr int PIECES = (chunk_kib(NEXT) + WAVES - 1) / WAVES;
+    static constexpr int SRC_OFF = chunk_off_kib(NEXT) * 1024;
+    static __device__ __forceinline__ void issue(const Ctx& c) {
+#pragma unroll
+        for (int p = 0; p < PIECES; ++p)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                c.wrsrc,
+                reinterpret_cast<lds_void*>(reinterpret_cast<lds_char*>(0) + c.s_wdst[NEXT & 1] + p * (WAVES * 1024)),
+                16, c.lane16, c.wave_goff + (SRC_OFF + p * WAVES * 1024), 0, 0);
+    }
+};
+
+// ReLU-mask halves of pair Q of forward layer A for this lane's point of block cb
+template <int A>
+__device__ __forceinline__ void load_mask(const State& st, int cb, int Q, u32x2 (&m)[2]) {
+    m[0] = u32x2{0u, 0u};
+    m[1] = u32x2{0u, 0u};
+    if (st.prow[cb] >= 0) {
+        const char* rp = st.acts + act_offset_bytes(A, st.P) + st.prow[cb] * (act_width(A) * 2) + 64 * Q + st.goff;
+        m[0] = *reinterpret_cast<const u32x2*>(rp);
+        m[1] = *reinterpret_cast<const u32x2*>(rp + 32);
+    }
+}
+
+// piece i of the epilogue of pair Q of backward layer B: mask, convert, and (on the
+// fragment's last word) store dY of forward layer 9-B
+template <int B, int Q>
+__device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], const u32x2 (&mask)[2][2],
+                                               ex8 (&dst)[2][8], State& st) {
+    constexpr BwdDesc D = bwd_desc(B);
+    constexpr int LOUT = 9 - B;
+    const int cb = i >> 2, j2 = i & 3;
+    float v0 = acc[cb][j2 >> 1][2 * (j2 & 1)], v1 = acc[cb][j2 >> 1][2 * (j2 & 1) + 1];
+    if constexpr (D.mask_act >= 0) {
+        const unsigned mw = mask[cb][j2 >> 1][j2 & 1];
+        v0 = (mw & 0xffffu) ? v0 : 0.f;
+        v1 = (mw >> 16) ? v1 : 0.f;
+    }
+    u32x4 w = __builtin_bit_cast(u32x4, dst[cb][Q]);
+    w[j2] = pack2(v0, v1);
+    dst[cb][Q] = __builtin_bit_cast(ex8, w);
+    if (j2 == 3 && st.prow[cb] >= 0) {
+        char* rp = st.dys + act_offset_bytes(LOUT, st.P) + st.prow[cb] * (act_width(LOUT) * 2) + 64 * Q + st.goff;
+        *reinterpret_cast<u32x2*>(rp) = u32x2{w[0], w[1]};
+        *reinterpret_cast<u32x2*>(rp + 32) = u32x2{w[2], w[3]};
+    }
+}
+
+template <int B, int C, int PB, int PQ>
+__device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8]) {
+    constexpr BwdDesc D = bwd_desc(B);
+    constexpr int KS_CHAIN = D.chain_k / 32;
+    constexpr int KS = KS_CHAIN + D.extra;
+    constexpr int CC = chunk_first(B) + C;
+    constexpr int NT = TPC;                         // every backward layer has a multiple of 4 row tiles
+    constexpr int F = NT * KS;
+    constexpr int AHEAD = 4;
+    constexpr int MT = 2 * KS;                      // MFMAs per row tile
+    constexpr int TOTAL_M = NT * MT;
+    // 8 epilogue pieces of the pending pair, then 8 of this chunk's first pair, spread
+    // over the MFMAs that exist (KS is 1 for b0, so pieces may share an MFMA there)
+    // a pending pair of the PREVIOUS layer is this layer's k-step PQ, first read by MFMA
+    // 2*PQ: all 8 pieces must have been issued before that
+    constexpr bool PEND_EARLY = TOTAL_M < 24 || (PB != B && PB >= 0 && 2 * PQ < 12);
+    constexpr int PEND_PER = PEND_EARLY ? 2 : 1;
+    constexpr int PEND_M0 = PEND_EARLY ? 0 : 2;
+    static_assert(PB < 0 || PB == B || 2 * PQ >= PEND_M0 + 8 / PEND_PER, "pending pair finished too late");
+    constexpr int PAIR_M0 = TOTAL_M >= 24 ? 2 * MT + 2 : 2 * MT;
+    constexpr int PAIR_PER = (TOTAL_M - PAIR_M0) >= 8 ? 1 : 2;
+    const unsigned wb = c.b_wread[CC & 1];
+    static_assert(bwd_mt(B) % TPC == 0, "row tiles per backward layer");
+
+    Stage<CC>::issue(c);
+
+    ex8 a[AHEAD];
+#pragma unroll
+    for (int f = 0; f < AHEAD && f < F; ++f) a[f] = lds_load<ex8>(wb, f * 1024);
+    // ReLU masks of the two pairs finished by this chunk (the second is handed on as pending)
+    u32x2 m0[2][2] = {}, m1[2][2] = {};
+    if constexpr (D.mask_act >= 0) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            load_mask<D.mask_act < 0 ? 0 : D.mask_act>(st, cb, 2 * C, m0[cb]);
+            load_mask<D.mask_act < 0 ? 0 : D.mask_act>(st, cb, 2 * C + 1, m1[cb]);
+        }
+    }
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __builtin_amdgcn_sched_barrier(0);
+
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int f = t * KS + ks;
+            const ex8 as = a[f % AHEAD];
+            if (f + AHEAD < F) a[f % AHEAD] = lds_load<ex8>(wb, (f + AHEAD) * 1024);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const int m = f * 2 + cb;
+                ex8 bs;
+                if (ks < KS_CHAIN) bs = in[cb][ks < KS_CHAIN ? ks : 0];
+                else bs = (B == 0) ? st.bx_rgb[cb] : st.bx_sig[cb];
+                acc[cb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as, bs, acc[cb][t], 0, 0, 0);
+                if constexpr (PB >= 0) {
+                    if (m >= PEND_M0 && m < PEND_M0 + 8 / PEND_PER) {
+#pragma unroll
+                        for (int k = 0; k < PEND_PER; ++k) {
+                            const int i = (m - PEND_M0) * PEND_PER + k;
+                            if constexpr (PB == B) epilogue_piece<PB, PQ>(i, st.pend, st.pmask, out, st);
+                            else epilogue_piece<PB, PQ>(i, st.pend, st.pmask, in, st);
+                        }
+                    }
+                }
+                if (m >= PAIR_M0 && m < PAIR_M0 + 8 / PAIR_PER) {
+                    const f32x4 pr[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
+#pragma unroll
+                    for (int k = 0; k < PAIR_PER; ++k)
+                        epilogue_piece<B, 2 * C>((m - PAIR_M0) * PAIR_PER + k, pr, m0, out, st);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        st.pend[cb][0] = acc[cb][NT - 2];
+        st.pend[cb][1] = acc[cb][NT - 1];
+        st.pmask[cb][0] = m1[cb][0];
+        st.pmask[cb][1] = m1[cb][1];
+    }
+    __syncthreads();
+}
+
+__host__ __device__ constexpr int prev_layer(int b, int C) { return C > 0 ? b : b - 1; }
+__host__ __device__ constexpr int prev_pair(int b, int C) {
+    return C > 0 ? 2 * C - 1 : (b > 0 ? bwd_mt(b - 1) / 2 - 1 : 0);
+}
+template <int B, int... Cs>
+__device__ __forceinline__ void run_layer_seq(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8],
+                                              std::integer_sequence<int, Cs...>) {
+    (chunk_step<B, Cs, prev_layer(B, Cs), prev_pair(B, Cs)>(c, st, in, out), ...);
+}
+template <int B>
+__device__ __forceinline__ void run_layer(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8]) {
+    run_layer_seq<B>(c, st, in, out, std::make_integer_sequence<int, layer_chunks(B)>{});
+}
+
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(BwdArgs a, long long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)smem;
+    Ctx c;
+    c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    c.lane = threadIdx.x & 63;
+    c.wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.image), 0, (int)BWD_IMAGE_BYTES, 0x00020000);
+    c.wave_goff = c.wave * 1024;
+    c.lane16 = c.lane * 16;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        c.b_wread[p] = LDS_W0 + p * LDS_WBUF + c.lane * 16;
+        c.s_wdst[p] = LDS_W0 + p * LDS_WBUF + c.wave * 1024;
+    }
+    Stage<NUM_CHUNKS - 1>::issue(c);
+    __syncthreads();
+
+    const int col = c.lane & 15, g = c.lane >> 4;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long tile_base = tile * TILE_PTS;
+        asm volatile("" : "+s"(c.wave_goff));
+        State st;
+        st.acts = a.acts;
+        st.dys = a.dys;
+        st.P = a.P;
+        st.goff = g * 8;
+        const __bf16 z = (__bf16)0.f;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const long long p = tile_base + c.wave * 32 + cb * 16 + col;
+            st.prow[cb] = p < a.P ? p : -1;
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (p < a.P) d = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);
+            // custom k-steps: lane group 0 carries drgb (elements 0..2) / dsigma (element 0)
+            const bool g0 = g == 0;
+            st.bx_rgb[cb] = ex8{g0 ? (__bf16)d[0] : z, g0 ? (__bf16)d[1] : z, g0 ? (__bf16)d[2] : z, z, z, z, z, z};
+            st.bx_sig[cb] = ex8{g0 ? (__bf16)d[3] : z, z, z, z, z, z, z, z};
+        }
+        run_layer<0>(c, st, st.X, st.X);     // d c    (b0 reads only drgb)        -> X[.][0..3]
+        run_layer<1>(c, st, st.X, st.Y);     // d h9
+        run_layer<2>(c, st, st.Y, st.X);     // d h8
+        run_layer<3>(c, st, st.X, st.Y);     // d h7
+        run_layer<4>(c, st, st.Y, st.X);     // d h6
+        run_layer<5>(c, st, st.X, st.Y);     // d h5
+        run_layer<6>(c, st, st.Y, st.X);     // d h4
+        run_layer<7>(c, st, st.X, st.Y);     // d h3
+        run_layer<8>(c, st, st.Y, st.X);     // d h2
+        run_layer<9>(c, st, st.X, st.Y);     // d h1
+        // the last pair of d h1 is still pending
+#pragma unroll
+        for (int i = 0; i < 8; ++i) epilogue_piece<9, bwd_mt(9) / 2 - 1>(i, st.pend, st.pmask, st.Y, st);
+    }
+}
+
+}  // namespace
+
+extern "C" int nerf_amd_launch_mlp_backward(const float* d_raw, const void* image, const void* acts, void* dys,
+                                            long long P, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (P <= 0) return 0;
+    BwdArgs a{d_raw, image, reinterpret_cast<const char*>(acts), reinterpret_cast<char*>(dys), P};
+    const long long ntiles = (P + TILE_PTS - 1) / TILE_PTS;
+    int dev = 0, cus = 256;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e != hipSuccess) return (int)e;
+    const long long grid = ntiles < cus ? ntiles : cus;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_mlp_bwd_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(nerf_mlp_bwd_kernel, dim3((unsigned)grid), dim3(WAVES * 64), LDS_TOTAL, stream, a, ntiles);
+    return (int)hipGetLastError();
+}

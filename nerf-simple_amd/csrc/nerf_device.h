@@ -26,6 +26,7 @@ struct MlpArgs {
     const void* packed;   // packed weight image
     float* raw;           // out [P,4]
     float* ts_out;        // rays mode: out [B,N] (may be NULL)
+    void* acts;           // training forward: saved bf16 activations (nerf_layout::acts_total_bytes), else NULL
     long long P;          // points = B*N
     long long ray_id0;    // global id of ray 0 (device RNG counter base)
     unsigned long long seed;

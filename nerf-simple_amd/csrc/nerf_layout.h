@@ -220,6 +220,58 @@ constexpr long long B16_IMAGE_OFFSET = ((long long)BF16_WEIGHT_KIB * 1024 + BIAS
 constexpr long long B16_IMAGE_BYTES = (long long)B16_WEIGHT_KIB * 1024 + B16_BIAS_FLOATS * 4;
 constexpr long long BF16_PACKED_TOTAL_BYTES = B16_IMAGE_OFFSET + B16_IMAGE_BYTES;
 
+// ---- backward (dX chain) image, bf16, 16-row tiles -------------------------------
+// Training backward of the dense layers: dX = W^T dY.  The same on-chip chaining
+// as the forward with the roles transposed: rows of an MFMA tile are INPUT
+// features of forward layer `wl`, the k dimension runs over its OUTPUT
+// features (the accumulators of the previous backward layer), columns are
+// points.  10 backward layers, in execution order:
+//   b0  C1^T        : k = drgb (3, one custom k-step)     -> d c      (128 rows, masked by c  > 0)
+//   b1  C0^T[:256]  : k = d c (128)                       -> d h9     (256 rows, no mask: L8 is linear)
+//   b2  [L2;sigma]^T: k = d h9 (256) + dsigma (1 k-step)  -> d h8     (masked by h8 > 0)
+//   b3..b4 L7^T,L6^T                                      -> d h7, d h6
+//   b5  L5^T[:256]  (skip layer, h part)                  -> d h5
+//   b6..b9 L4^T..L1^T                                     -> d h4 .. d h1
+// (L0^T is never needed: the inputs carry no gradient.)
+constexpr int NUM_BWD = 10;
+struct BwdDesc {
+    int wl;        // forward layer whose weight is transposed
+    int rows;      // rows of dX = input features taken from that layer (h part only)
+    int chain_k;   // k taken from the previous backward layer's accumulators
+    int extra;     // 1: one more k-step fed from d_raw (b0: drgb, b2: dsigma)
+    int mask_act;  // saved forward activation (internal layer index) gating dX, -1 = none
+};
+NL_HD constexpr BwdDesc bwd_desc(int b) {
+    return b == 0 ? BwdDesc{10, 128, 0, 1, 9}
+         : b == 1 ? BwdDesc{9, 256, 128, 0, -1}
+         : b == 2 ? BwdDesc{8, 256, 256, 1, 7}
+         :          BwdDesc{10 - b, 256, 256, 0, 9 - b};      // b3: wl 7, mask act 6 ... b9: wl 1, mask act 0
+}
+NL_HD constexpr int bwd_ks(int b) { return bwd_desc(b).chain_k / 32 + bwd_desc(b).extra; }
+NL_HD constexpr int bwd_mt(int b) { return bwd_desc(b).rows / 16; }
+// forward OUTPUT row (of layer wl) that sits at k position (ks, g, j); -1 = padding
+NL_HD constexpr int bwd_src_out(int b, int ks, int g, int j) {
+    const BwdDesc d = bwd_desc(b);
+    if (ks < d.chain_k / 32) return chain_feat_b16(ks, g, j);
+    // custom k-step: lane group 0 carries drgb (b0: rows 0..2) or dsigma (b2: row 256)
+    return b == 0 ? ((g == 0 && j < 3) ? j : -1) : ((g == 0 && j == 0) ? 256 : -1);
+}
+NL_HD constexpr int bwd_layer_off_kib(int b) {
+    int o = 0;
+    for (int i = 0; i < b; ++i) o += bwd_mt(i) * bwd_ks(i);
+    return o;
+}
+constexpr int BWD_WEIGHT_KIB = bwd_layer_off_kib(NUM_BWD);           // 1112
+constexpr long long BWD_IMAGE_BYTES = (long long)BWD_WEIGHT_KIB * 1024;
+
+// saved forward activations (bf16, row-major [P, width]): index = internal layer
+// L0..L7 post-ReLU (256), L8 = h9 linear (256), L9 = c post-ReLU (128)
+NL_HD constexpr int act_width(int L) { return L == 9 ? 128 : 256; }
+NL_HD constexpr long long act_offset_bytes(int L, long long P) { return (long long)L * P * 512; }
+NL_HD constexpr long long acts_total_bytes(long long P) { return 9 * P * 512 + P * 256; }
+// saved backward pre-activation gradients dY (bf16, row-major), same indexing:
+// dY[L] has the width of layer L's output
+
 // ---- packed f32 image -----------------------------------------------------
 // 16-row output tiles (mfma_f32_16x16x4f32).  chunk = (layer, t): K/4 k-steps
 // x 64 lanes x 4 B, stored [ks/4][lane][4] so one ds_read_b128 per lane covers

@@ -45,6 +45,23 @@ __global__ void pack_b16_kernel(const float* __restrict__ params, T* __restrict_
     }
 }
 
+// backward image: [tile (bwd layer b, rt)][k-step][lane][8 bf16] = W_wl[out(ks,g,j)][in = 16rt + r]
+__global__ void pack_bwd_kernel(const float* __restrict__ params, __bf16* __restrict__ out) {
+    const long long total = (long long)BWD_WEIGHT_KIB * 512;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const int kib = (int)(e >> 9);
+        int b = 0;
+        while (b + 1 < NUM_BWD && kib >= bwd_layer_off_kib(b + 1)) ++b;
+        const int rel = kib - bwd_layer_off_kib(b);
+        const int rt = rel / bwd_ks(b), s = rel % bwd_ks(b);
+        const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
+        const int in_col = 16 * rt + (lane & 15), g = lane >> 4;
+        const int o = bwd_src_out(b, s, g, j);
+        out[e] = (__bf16)(o < 0 ? 0.f : weight_at(params, bwd_desc(b).wl, o, in_col));
+    }
+}
+
 // f32 image: [chunk (layer, t)][k-step/4][lane][4 f32]
 __global__ void pack_f32_kernel(const float* __restrict__ params, float* __restrict__ out) {
     const long long total = (long long)F32_WEIGHT_KIB * 256;      // floats
@@ -97,6 +114,10 @@ extern "C" int nerf_amd_launch_pack(const float* params, void* packed, int preci
         // 16-row bias table == the f32 path's (natural row order, 16 per tile)
         hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params,
                            reinterpret_cast<float*>(img16 + (long long)B16_WEIGHT_KIB * 1024), 1);
+    } else if (precision == 3) {
+        // training backward image (bf16)
+        hipLaunchKernelGGL(pack_bwd_kernel, dim3(1024), dim3(256), 0, stream, params,
+                           reinterpret_cast<__bf16*>(packed));
     } else if (precision == 2) {
         // fp16: the 16-row image only, at offset 0
         hipLaunchKernelGGL(pack_b16_kernel<_Float16>, dim3(1024), dim3(256), 0, stream, params,

@@ -1,22 +1,24 @@
 """Training-side entry points: the step of reference train.py:47-57 on the GPU.
 
-What runs where in a training step (BASELINE config 5):
+What runs where in a training step (BASELINE config 5), 16-bit precision (default):
 
-  sampling + point assembly + positional encoding   HIP  nerf_amd_sample_encode
-  12 dense layers, forward and backward             library GEMMs (hipBLASLt / rocBLAS through
-                                                    torch.nn.functional.linear under autograd),
-                                                    bf16 operands via autocast or plain fp32
+  sampling + encoding + 12 dense layers, forward    HIP  nerf_amd_mlp_forward_train (the fused
+                                                    inference kernel, also saving bf16 activations)
   sigma -> alpha compositing, forward               HIP  nerf_amd_volume_render
   compositing, backward (suffix-sum scan)           HIP  nerf_amd_volume_render_backward
+  dense layers, backward dX chain (on-chip)         HIP  nerf_amd_mlp_backward
+  dense layers, dW = dY^T X and db = sum dY         plain GEMMs / reductions over the point
+                                                    dimension: vendor library (torch.mm)
   gradient exchange                                 RCCL all-reduce of one flat bucket (parallel.py)
   optimizer                                         torch.optim.Adam (reference train.py:43)
 
-The dense layers' backward is a set of plain GEMMs (dW = dY^T X over the point
-dimension, dX = dY W), which is what the vendor library is for; a fused
-hand-written backward that keeps the dX chain on-chip like the forward kernel
-is the planned replacement.  Inference never comes here:
-without gradients the fused forward kernel runs (utils/nets.py, utils/rendering.py).
+precision='fp32' keeps everything in fp32: HIP sampling/encoding and compositor,
+the dense layers through torch.nn.functional.linear under autograd (library
+GEMMs); that path is the one pinned bit-tight against golden G6.  Inference never
+comes here: without gradients the fused forward kernel runs.
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -109,11 +111,106 @@ def nerf_forward_autograd(net, v, precision):
     return _dense_layers(net, x, d, precision)
 
 
+# --------------------------------------------------------------------------
+# fused dense layers: HIP forward (saving activations) + HIP dX chain + library dW
+# --------------------------------------------------------------------------
+def _mm_t(a, b):
+    """a^T @ b for bf16 [P,m], [P,n] -> fp32 [m,n]: one library GEMM over the point
+    dimension with fp32 accumulation (fp32 output where the build supports it)."""
+    try:
+        return torch.mm(a.t(), b, out_dtype=torch.float32)
+    except (TypeError, RuntimeError):
+        return torch.mm(a.t(), b).float()
+
+
+class _FusedDense(torch.autograd.Function):
+    """(rays, jitter) -> raw [B,N,4], ts [B,N] through nerf_amd_mlp_forward_train;
+    backward: nerf_amd_mlp_backward for every layer's pre-activation gradient, then
+    dW / db as GEMMs / column sums.  Parameter order = state_dict order."""
+
+    @staticmethod
+    def forward(ctx, net, rays, jit, tbins, flags, seed, ray_id0, N, *params):
+        lib = _lib.lib()
+        B, dev = rays.size(0), rays.device
+        P = B * N
+        packed = net.packed_weights(_lib.BF16)
+        raw = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
+        ts = torch.empty((B, N), dtype=torch.float32, device=dev)
+        acts = torch.empty(int(lib.nerf_amd_train_activation_bytes(P)), dtype=torch.uint8, device=dev)
+        posx = torch.empty((P, 63), dtype=torch.float32, device=dev)
+        posd = torch.empty((P, 27), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr(dev)
+            _lib.check(lib.nerf_amd_mlp_forward_train(
+                _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(tbins), _lib.ptr(packed), flags, int(seed), int(ray_id0),
+                _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(acts), B, N, st), "nerf_amd_mlp_forward_train")
+            # encoder outputs in the reference's column order: the inputs of the dW GEMMs of
+            # layers_0.0 / skip_conn_layer / color_fc.0 (same sample positions: ts given)
+            _lib.check(lib.nerf_amd_sample_encode(
+                _lib.ptr(rays), _lib.ptr(ts), None, _lib.FLAG_TS_GIVEN, 0, 0,
+                _lib.ptr(posx), _lib.ptr(posd), None, B, N, st), "nerf_amd_sample_encode")
+        ctx.net, ctx.P = net, P
+        ctx.save_for_backward(acts, posx.to(torch.bfloat16), posd.to(torch.bfloat16))
+        ctx.mark_non_differentiable(ts)
+        return raw, ts
+
+    @staticmethod
+    def backward(ctx, g_raw, _g_ts):
+        lib = _lib.lib()
+        acts, posx, posd = ctx.saved_tensors
+        net, P = ctx.net, ctx.P
+        dev = acts.device
+        g = g_raw.reshape(P, 4).contiguous().float()
+        image = net.packed_weights(_lib.BF16_BWD)
+        dys = torch.empty_like(acts)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_mlp_backward(_lib.ptr(g), _lib.ptr(image), _lib.ptr(acts), _lib.ptr(dys), P,
+                                                 _lib.stream_ptr(dev)), "nerf_amd_mlp_backward")
+
+        def view(buf, L):
+            width = 128 if L == 9 else 256
+            off = L * P * 512
+            return buf[off:off + P * width * 2].view(torch.bfloat16).view(P, width)
+
+        act = [view(acts, L) for L in range(10)]
+        dy = [view(dys, L) for L in range(10)]
+        gb = g.to(torch.bfloat16)
+        drgb, dsig = gb[:, :3].contiguous(), gb[:, 3:4].contiguous()
+
+        def bsum(t):
+            return t.sum(0, dtype=torch.float32)
+
+        grads = [
+            _mm_t(dy[0], posx), bsum(dy[0]),                                   # layers_0.0
+            _mm_t(dy[1], act[0]), bsum(dy[1]),                                 # layers_0.2
+            _mm_t(dy[2], act[1]), bsum(dy[2]),                                 # layers_0.4
+            _mm_t(dy[3], act[2]), bsum(dy[3]),                                 # layers_0.6
+            _mm_t(dy[4], act[3]), bsum(dy[4]),                                 # layers_0.8
+            torch.cat([_mm_t(dy[5], act[4]), _mm_t(dy[5], posx)], dim=1), bsum(dy[5]),   # skip_conn_layer.0 [h ; x]
+            _mm_t(dy[6], act[5]), bsum(dy[6]),                                 # layers_1.0
+            _mm_t(dy[7], act[6]), bsum(dy[7]),                                 # layers_1.2
+            _mm_t(dsig, act[7]), g[:, 3].sum().reshape(1),                     # sigma_fc.0
+            _mm_t(dy[8], act[7]), bsum(dy[8]),                                 # layers_2
+            torch.cat([_mm_t(dy[9], act[8]), _mm_t(dy[9], posd)], dim=1), bsum(dy[9]),   # color_fc.0 [h ; d]
+            _mm_t(drgb, act[9]), g[:, :3].sum(0),                              # color_fc.2
+        ]
+        return (None,) * 8 + tuple(grads)
+
+
+def _fused_training_enabled(precision):
+    return _lib.precision_code(precision) != _lib.F32 and os.environ.get("NERF_AMD_TRAIN_FUSED", "1") != "0"
+
+
 def render_nerf_autograd(rays, net, N, tn, tf, jit, flags, precision, seed, ray_id0):
     """render_nerf (reference utils/rendering.py:13-45) with gradients to the
     parameters of ``net``; returns the same 5-tuple."""
     from .utils.rendering import _tbins
     B, dev = rays.size(0), rays.device
+    if _fused_training_enabled(precision):
+        params = [p for _, p in net.named_parameters()]
+        raw, ts = _FusedDense.apply(net, rays, jit, _tbins(tn, tf, N, dev), flags, seed, ray_id0, N, *params)
+        dn = rays[:, 3:] / torch.norm(rays[:, 3:], dim=1, keepdim=True)
+        return _VolumeRender.apply(raw, ts, dn)
     lib = _lib.lib()
     P = B * N
     posx = torch.empty((P, 63), dtype=torch.float32, device=dev)

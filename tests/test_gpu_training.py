@@ -129,3 +129,48 @@ def test_bf16_training_reduces_loss(dev, synthetic, oracle):
     cos = torch.nn.functional.cosine_similarity(grads["fp32"], grads["bf16"], dim=0)
     print("cos(grad fp32, grad bf16) =", float(cos))
     assert cos > 0.99
+
+
+def _grads_of(dev, synthetic, kind, precision, fused, rays, gt, u, N):
+    import os
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.training import train_step
+    os.environ["NERF_AMD_TRAIN_FUSED"] = "1" if fused else "0"
+    try:
+        net = Nerf(precision=precision).to(dev)
+        net.load_state_dict(synthetic.synthetic_state_dict(0, kind))
+        opt = torch.optim.SGD(net.parameters(), lr=0.0)
+        loss = train_step(net, opt, rays, gt, N, u=u)
+        return float(loss), {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}
+    finally:
+        os.environ.pop("NERF_AMD_TRAIN_FUSED", None)
+
+
+@pytest.mark.parametrize("kind", ["default", "structured"])
+def test_fused_backward_matches_autograd(dev, synthetic, kind):
+    """The hand-written training path (fused forward saving activations, HIP dX chain,
+    library dW GEMMs) against torch autograd over library GEMMs, tensor by tensor:
+    fp32 autograd is the reference; bf16 autograd shows what 8-bit mantissas cost."""
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
+    rays = camera_rays([pose], [24, 24, synthetic.focal_from_fov(24)]).to(dev)       # 576 rays: a ragged tile
+    gt = torch.rand(rays.shape[0], 3, generator=torch.Generator().manual_seed(2)).to(dev)
+    N = 64
+    u = torch.rand(rays.shape[0], N, generator=torch.Generator().manual_seed(3)).to(dev)
+    l32, g32 = _grads_of(dev, synthetic, kind, "fp32", False, rays, gt, u, N)
+    l16, g16 = _grads_of(dev, synthetic, kind, "bf16", False, rays, gt, u, N)
+    lf, gf = _grads_of(dev, synthetic, kind, "bf16", True, rays, gt, u, N)
+    assert abs(lf - l32) <= 2e-2 * abs(l32) + 1e-6
+    worst = 1.0
+    for k in g32:
+        a, b, c = g32[k].reshape(-1), gf[k].reshape(-1), g16[k].reshape(-1)
+        cos_f = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
+        cos_a = float(torch.nn.functional.cosine_similarity(a, c, dim=0))
+        ratio = float(b.norm() / a.norm())
+        print(f"{kind} {k:28s} cos(fused,fp32)={cos_f:.5f} cos(autograd-bf16,fp32)={cos_a:.5f} |g| ratio={ratio:.4f}")
+        worst = min(worst, cos_f)
+        assert cos_f >= 0.98, k
+        assert 0.9 <= ratio <= 1.1, k
+    allf = torch.cat([gf[k].reshape(-1) for k in g32])
+    all32 = torch.cat([g32[k].reshape(-1) for k in g32])
+    assert float(torch.nn.functional.cosine_similarity(allf, all32, dim=0)) >= 0.995
