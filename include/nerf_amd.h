@@ -188,6 +188,20 @@ int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* t
 int nerf_amd_mlp_backward(const float* d_raw, const void* bwd_image, const void* acts,
                           void* dys, int64_t P, void* stream);
 
+/* Encoder outputs as the dW GEMM wants them: bf16, posx64[P,64] (col 63 zero),
+ * posd32[P,32] (cols 27..31 zero); otherwise as nerf_amd_sample_encode. */
+int nerf_amd_sample_encode_bf16(const float* rays, const float* u, const float* tbins,
+                                uint32_t flags, uint64_t seed, int64_t ray_id0,
+                                void* posx64, void* posd32, float* ts, int64_t B, int N, void* stream);
+/* All 24 parameter gradients of the step in ONE flat fp32 vector `grads`[595844]
+ * (state_dict order; zeroed by the call): dW_L = dys[L]^T @ input_L as split-K
+ * GEMMs over the points, db_L = column sums.  The vector is also the bucket of the
+ * data-parallel all-reduce.  scratch: nerf_amd_param_gradients_scratch_bytes(P). */
+int64_t nerf_amd_param_gradients_scratch_bytes(int64_t P);
+int nerf_amd_param_gradients(const float* d_raw, const void* acts, const void* dys,
+                             const void* posx64, const void* posd32, void* scratch,
+                             float* grads, int64_t P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,6 +29,9 @@ int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, long long, hipStream_t);
+int nerf_amd_launch_sample_encode_bf16(const MlpArgs*, void*, void*, hipStream_t);
+int nerf_amd_launch_param_gradients(const float*, const void*, const void*, const void*, const void*, void*, float*,
+                                    long long, hipStream_t);
 }
 
 namespace {
@@ -312,6 +315,29 @@ int nerf_amd_mlp_backward(const float* d_raw, const void* bwd_image, const void*
     if (P == 0) return 0;
     if (!d_raw || !bwd_image || !acts || !dys) return NERF_AMD_EINVAL;
     return nerf_amd_launch_mlp_backward(d_raw, bwd_image, acts, dys, P, S(stream));
+}
+
+int nerf_amd_sample_encode_bf16(const float* rays, const float* u, const float* tbins, uint32_t flags,
+                                uint64_t seed, int64_t ray_id0, void* posx64, void* posd32, float* ts, int64_t B,
+                                int N, void* stream) {
+    if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (!rays || !posx64 || !posd32) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+    MlpArgs a{};
+    a.rays = rays; a.u = u; a.tbins = tbins; a.ts_out = ts;
+    a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
+    return nerf_amd_launch_sample_encode_bf16(&a, posx64, posd32, S(stream));
+}
+
+int64_t nerf_amd_param_gradients_scratch_bytes(int64_t P) { return P < 0 ? (int64_t)NERF_AMD_EINVAL : P * 64; }
+
+int nerf_amd_param_gradients(const float* d_raw, const void* acts, const void* dys, const void* posx64,
+                             const void* posd32, void* scratch, float* grads, int64_t P, void* stream) {
+    if (P < 0 || !grads) return NERF_AMD_EINVAL;
+    if (P > 0 && (!d_raw || !acts || !dys || !posx64 || !posd32 || !scratch)) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_param_gradients(d_raw, acts, dys, posx64, posd32, scratch, grads, P, S(stream));
 }
 
 }  // extern "C"

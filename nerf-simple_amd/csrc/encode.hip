@@ -78,6 +78,29 @@ __global__ void sample_encode_kernel(MlpArgs a, float* __restrict__ posx, float*
     }
 }
 
+// The same front end for the fused training path: bf16 outputs padded to the dW GEMM's
+// operand widths, posx [P,64] (col 63 = 0) and posd [P,32] (cols 27..31 = 0).
+__global__ void sample_encode_bf16_kernel(MlpArgs a, __bf16* __restrict__ posx, __bf16* __restrict__ posd) {
+    constexpr int C = 64 + 32;
+    const long long total = a.P * C;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        const long long p = e / C;
+        int col = (int)(e - p * C);
+        const PointIn pt = fetch_point_rays(a, p);
+        if (col == 0 && a.ts_out) a.ts_out[p] = pt.t;
+        const float xyz[3] = {pt.x, pt.y, pt.z}, dd[3] = {pt.d1, pt.d2, pt.d3};
+        if (col < 64) {
+            const float v = col < 3 ? xyz[col] : col < 63 ? enc_value(xyz[(col - 3) / 20], (col - 3) % 20) : 0.f;
+            posx[p * 64 + col] = (__bf16)v;
+        } else {
+            col -= 64;
+            const float v = col < 3 ? dd[col] : col < 27 ? enc_value(dd[(col - 3) / 8], (col - 3) % 8) : 0.f;
+            posd[p * 32 + col] = (__bf16)v;
+        }
+    }
+}
+
 __host__ int grid_for(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 256 * 32 ? 256 * 32 : g));
@@ -106,5 +129,13 @@ extern "C" int nerf_amd_launch_sample_encode(const MlpArgs* args, float* posx, f
     (void)hipGetLastError();
     if (args->P == 0) return 0;
     hipLaunchKernelGGL(sample_encode_kernel, dim3(grid_for(args->P * 90)), dim3(256), 0, stream, *args, posx, posd);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nerf_amd_launch_sample_encode_bf16(const MlpArgs* args, void* posx64, void* posd32, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (args->P == 0) return 0;
+    hipLaunchKernelGGL(sample_encode_bf16_kernel, dim3(grid_for(args->P * 96)), dim3(256), 0, stream, *args,
+                       reinterpret_cast<__bf16*>(posx64), reinterpret_cast<__bf16*>(posd32));
     return (int)hipGetLastError();
 }

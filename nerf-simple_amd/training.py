@@ -114,19 +114,11 @@ def nerf_forward_autograd(net, v, precision):
 # --------------------------------------------------------------------------
 # fused dense layers: HIP forward (saving activations) + HIP dX chain + library dW
 # --------------------------------------------------------------------------
-def _mm_t(a, b):
-    """a^T @ b for bf16 [P,m], [P,n] -> fp32 [m,n]: one library GEMM over the point
-    dimension with fp32 accumulation (fp32 output where the build supports it)."""
-    try:
-        return torch.mm(a.t(), b, out_dtype=torch.float32)
-    except (TypeError, RuntimeError):
-        return torch.mm(a.t(), b).float()
-
-
 class _FusedDense(torch.autograd.Function):
     """(rays, jitter) -> raw [B,N,4], ts [B,N] through nerf_amd_mlp_forward_train;
     backward: nerf_amd_mlp_backward for every layer's pre-activation gradient, then
-    dW / db as GEMMs / column sums.  Parameter order = state_dict order."""
+    nerf_amd_param_gradients (split-K GEMMs + column sums) into ONE flat fp32
+    vector in state_dict order, handed back to autograd as 24 views."""
 
     @staticmethod
     def forward(ctx, net, rays, jit, tbins, flags, seed, ray_id0, N, *params):
@@ -137,20 +129,21 @@ class _FusedDense(torch.autograd.Function):
         raw = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
         ts = torch.empty((B, N), dtype=torch.float32, device=dev)
         acts = torch.empty(int(lib.nerf_amd_train_activation_bytes(P)), dtype=torch.uint8, device=dev)
-        posx = torch.empty((P, 63), dtype=torch.float32, device=dev)
-        posd = torch.empty((P, 27), dtype=torch.float32, device=dev)
+        posx = torch.empty((P, 64), dtype=torch.bfloat16, device=dev)
+        posd = torch.empty((P, 32), dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
             st = _lib.stream_ptr(dev)
             _lib.check(lib.nerf_amd_mlp_forward_train(
                 _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(tbins), _lib.ptr(packed), flags, int(seed), int(ray_id0),
                 _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(acts), B, N, st), "nerf_amd_mlp_forward_train")
-            # encoder outputs in the reference's column order: the inputs of the dW GEMMs of
+            # encoder outputs in the reference's column order: the inputs of the dW products of
             # layers_0.0 / skip_conn_layer / color_fc.0 (same sample positions: ts given)
-            _lib.check(lib.nerf_amd_sample_encode(
+            _lib.check(lib.nerf_amd_sample_encode_bf16(
                 _lib.ptr(rays), _lib.ptr(ts), None, _lib.FLAG_TS_GIVEN, 0, 0,
-                _lib.ptr(posx), _lib.ptr(posd), None, B, N, st), "nerf_amd_sample_encode")
+                _lib.ptr(posx), _lib.ptr(posd), None, B, N, st), "nerf_amd_sample_encode_bf16")
         ctx.net, ctx.P = net, P
-        ctx.save_for_backward(acts, posx.to(torch.bfloat16), posd.to(torch.bfloat16))
+        ctx.shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(acts, posx, posd)
         ctx.mark_non_differentiable(ts)
         return raw, ts
 
@@ -163,37 +156,22 @@ class _FusedDense(torch.autograd.Function):
         g = g_raw.reshape(P, 4).contiguous().float()
         image = net.packed_weights(_lib.BF16_BWD)
         dys = torch.empty_like(acts)
+        flat = torch.empty(int(lib.nerf_amd_param_count()), dtype=torch.float32, device=dev)
+        scratch = torch.empty(max(int(lib.nerf_amd_param_gradients_scratch_bytes(P)), 16), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
-            _lib.check(lib.nerf_amd_mlp_backward(_lib.ptr(g), _lib.ptr(image), _lib.ptr(acts), _lib.ptr(dys), P,
-                                                 _lib.stream_ptr(dev)), "nerf_amd_mlp_backward")
-
-        def view(buf, L):
-            width = 128 if L == 9 else 256
-            off = L * P * 512
-            return buf[off:off + P * width * 2].view(torch.bfloat16).view(P, width)
-
-        act = [view(acts, L) for L in range(10)]
-        dy = [view(dys, L) for L in range(10)]
-        gb = g.to(torch.bfloat16)
-        drgb, dsig = gb[:, :3].contiguous(), gb[:, 3:4].contiguous()
-
-        def bsum(t):
-            return t.sum(0, dtype=torch.float32)
-
-        grads = [
-            _mm_t(dy[0], posx), bsum(dy[0]),                                   # layers_0.0
-            _mm_t(dy[1], act[0]), bsum(dy[1]),                                 # layers_0.2
-            _mm_t(dy[2], act[1]), bsum(dy[2]),                                 # layers_0.4
-            _mm_t(dy[3], act[2]), bsum(dy[3]),                                 # layers_0.6
-            _mm_t(dy[4], act[3]), bsum(dy[4]),                                 # layers_0.8
-            torch.cat([_mm_t(dy[5], act[4]), _mm_t(dy[5], posx)], dim=1), bsum(dy[5]),   # skip_conn_layer.0 [h ; x]
-            _mm_t(dy[6], act[5]), bsum(dy[6]),                                 # layers_1.0
-            _mm_t(dy[7], act[6]), bsum(dy[7]),                                 # layers_1.2
-            _mm_t(dsig, act[7]), g[:, 3].sum().reshape(1),                     # sigma_fc.0
-            _mm_t(dy[8], act[7]), bsum(dy[8]),                                 # layers_2
-            torch.cat([_mm_t(dy[9], act[8]), _mm_t(dy[9], posd)], dim=1), bsum(dy[9]),   # color_fc.0 [h ; d]
-            _mm_t(drgb, act[9]), g[:, :3].sum(0),                              # color_fc.2
-        ]
+            st = _lib.stream_ptr(dev)
+            _lib.check(lib.nerf_amd_mlp_backward(_lib.ptr(g), _lib.ptr(image), _lib.ptr(acts), _lib.ptr(dys), P, st),
+                       "nerf_amd_mlp_backward")
+            _lib.check(lib.nerf_amd_param_gradients(_lib.ptr(g), _lib.ptr(acts), _lib.ptr(dys), _lib.ptr(posx),
+                                                    _lib.ptr(posd), _lib.ptr(scratch), _lib.ptr(flat), P, st),
+                       "nerf_amd_param_gradients")
+        grads, off = [], 0
+        for shp in ctx.shapes:
+            n = 1
+            for s_ in shp:
+                n *= s_
+            grads.append(flat[off:off + n].view(shp))
+            off += n
         return (None,) * 8 + tuple(grads)
 
 
