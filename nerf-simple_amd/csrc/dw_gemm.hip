@@ -10,7 +10,7 @@
 // their slow dimension: a "TN" GEMM with M, N <= 256 and K = P ~ 10^5..10^6.
 // The vendor library runs this shape on 16 workgroups; here:
 //   * ONE launch covers all 14 products; each gets a share of the ~256
-//     workgroups proportional to its M*N (split-K over the points);
+//     workgroups proportional to the bytes it streams (split-K over the points);
 //   * a workgroup (8 waves) owns the full 256x256 output of its product in
 //     registers and walks its K slice in slabs of 64 points, staged
 //     HBM -> registers -> LDS (row-major, rows padded to 576 B), double buffered;
@@ -273,15 +273,17 @@ extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* a
     add(dy(9), 128, 128, posd, 32, 32, OFF_C0_W + 256, 283, 0, 128, 27);                  //                      d part
     add(dsr, 32, 32, act(9), 128, 128, OFF_C1_W, 128, 0, 3, 128);                         // color_fc.2 (rows 0..2)
     t.n = n;
-    // workgroups per product, proportional to its arithmetic, about one per CU in total
+    // workgroups per product, about one per CU in total.  The kernel is HBM-bound, so a product's
+    // cost per slab is the bytes it streams, (M + N) * 2 per point, not its M*N flops (sizing by
+    // flops left the thin products -- 32 x 256 reads as much of X as 256 x 256 -- as a 2 ms tail)
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     double total = 0;
-    for (int i = 0; i < n; ++i) total += (double)t.d[i].M * t.d[i].N;
+    for (int i = 0; i < n; ++i) total += (double)(t.d[i].M + t.d[i].N);
     const long long nslab = (P + SLAB - 1) / SLAB;
     int wg = 0;
     for (int i = 0; i < n; ++i) {
-        long long w = (long long)((double)t.d[i].M * t.d[i].N / total * cus + 0.5);
+        long long w = (long long)((double)(t.d[i].M + t.d[i].N) / total * cus + 0.5);
         if (w < 1) w = 1;
         if (w > nslab) w = nslab;
         t.d[i].wg0 = wg;
