@@ -188,6 +188,13 @@ def main():
         achieved = launch_samples * FLOP_PER_SAMPLE / (mlp_ms * 1e-3) / 1e12
         kern = {"bf16": "nerf_mlp_bf16_16_kernel<true>", "fp16": "nerf_mlp_f16_16_kernel<true>",
                 "fp32": "nerf_mlp_f32_kernel<true>"}[args.precision]
+        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3
+        # cannot run inside this process): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 wide-read correction),
+        # 1.6e6 KB + 2 x 37.3e3 KB for the full 81.92 M-sample launch; algorithmic: 20 B/sample written.
+        traffic, traffic_src = None, None
+        if world == 1 and args.precision == "bf16":
+            traffic = (1.6e6 + 2 * 37.3e3) * 1024
+            traffic_src = "profiles/r01c_bench_rocprofv3_summary.txt (WRITE_SIZE + 2*FETCH_SIZE, same command)"
         res = {
             "metric": "ray-samples/sec at 800x800x128", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -199,7 +206,8 @@ def main():
                        "jitter": "device counter RNG", "weights": "synthetic_state_dict(0,'structured')",
                        "parallelism": f"rays sharded x{world}" + (" + RCCL all_gather of [rgb,disp]" if world > 1 else "")},
             "roofline": {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak / 1e12,
-                         "unit": "TFLOP/s", "frac": achieved * 1e12 / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved * 1e12 / peak, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "kernel_ms": mlp_ms, "flop_per_sample": FLOP_PER_SAMPLE,
                          "samples_per_launch": launch_samples},
         }

@@ -110,3 +110,55 @@ def test_host_camera_helpers(golden):
     assert np.array_equal(torch.stack(xyz.poses_to_render(4, -30, 5)).numpy(), g["poses5"])
     pose = torch.from_numpy(xyz.spherical_to_pose(4, -30, 40)).float()
     assert np.array_equal(xyz.camera_rays([pose], [100, 100, float(g["f"])]).numpy(), g["rays100_phi40"])
+
+
+def test_abi_argument_errors(lib):
+    """Error behaviour of the C ABI (include/nerf_amd.h): bad arguments return
+    NERF_AMD_EINVAL / EUNSUP before anything is launched -- no exception, no exit, and
+    no GPU needed to observe it."""
+    EINVAL, EUNSUP = -1, -2
+    null = None
+    one = ctypes.c_void_p(16)                     # a non-null dummy: never dereferenced on these paths
+    assert lib.nerf_amd_pack_weights(null, one, 1, null) == EINVAL
+    assert lib.nerf_amd_pack_weights(one, one, 9, null) == EINVAL
+    assert lib.nerf_amd_gamma(one, 1, one, -1, 4, null) == EINVAL
+    assert lib.nerf_amd_gamma(null, 1, null, 0, 4, null) == 0          # empty input: nothing to do
+    assert lib.nerf_amd_positional_encoder(null, one, one, 5, 10, 4, null) == EINVAL
+    assert lib.nerf_amd_mlp_forward(one, one, one, 8, 7, null) == EINVAL          # unknown precision
+    assert lib.nerf_amd_mlp_forward(null, one, one, 8, 1, null) == EINVAL
+    assert lib.nerf_amd_mlp_forward(null, null, null, 0, 1, null) == 0
+    assert lib.nerf_amd_volume_render(one, one, one, 2, one, one, null, one, null, 4, 8, null) == EINVAL  # stride < 3
+    assert lib.nerf_amd_volume_render(one, one, one, 3, one, one, null, one, null, 4, 0, null) == EINVAL  # N = 0
+    assert lib.nerf_amd_volume_render_backward(one, one, one, 3, one, null, null, null, null, one, 4, 1024, null) == EUNSUP
+    assert lib.nerf_amd_render_forward(one, null, one, one, 1, 0, 0, 0, one, one, null, one, null, one, 4, 8, null) == EINVAL  # no jitter
+    assert lib.nerf_amd_render_forward(one, one, null, one, 1, 0, 0, 0, one, one, null, one, null, one, 4, 8, null) == EINVAL  # no tbins
+    assert lib.nerf_amd_render_forward(one, one, one, one, 1, 0, 0, 0, one, one, null, one, null, null, 4, 8, null) == EINVAL  # no workspace
+    assert lib.nerf_amd_sample_pdf(one, one, one, 0, 0, 0, one, 4, 2, 8, null) == EUNSUP      # Nc < 3
+    assert lib.nerf_amd_sample_pdf(one, one, one, 0, 0, 0, one, 4, 300, 8, null) == EUNSUP    # Nc > 256
+    assert lib.nerf_amd_generate_rays(one, 10, 10, ctypes.c_float(5.0), 90, 20, one, null) == EINVAL   # past the image
+    assert lib.nerf_amd_generate_rays(one, 10, 10, ctypes.c_float(0.0), 0, 10, one, null) == EINVAL    # f <= 0
+    assert lib.nerf_amd_mlp_backward(null, one, one, one, 16, null) == EINVAL
+    assert lib.nerf_amd_param_gradients(one, one, one, one, one, one, null, 16, null) == EINVAL
+    assert lib.nerf_amd_train_activation_bytes(1000) == 1000 * (9 * 512 + 256)
+    assert lib.nerf_amd_packed_bytes(3) == 1112 * 1024
+    assert lib.nerf_amd_packed_bytes(2) == 1172 * 1024 + 2464 * 4
+
+
+def test_checkpoint_roundtrip(tmp_path, synthetic):
+    """N4: checkpoints are the reference's format (24-key state_dict, strict load)."""
+    import torch
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils import checkpoint
+    a = Nerf()
+    a.load_state_dict(synthetic.synthetic_state_dict(3, "default"))
+    path = checkpoint.save_checkpoint(a, str(tmp_path / "ckpt.pth"))
+    raw = torch.load(path, weights_only=True)
+    assert list(raw.keys()) == [k for k, _ in synthetic.PARAM_SPECS]
+    b = checkpoint.load_checkpoint(Nerf(), path)
+    for (k, x), (_, y) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.equal(x, y), k
+    bad = dict(raw)
+    bad.pop("sigma_fc.0.bias")
+    torch.save(bad, str(tmp_path / "bad.pth"))
+    with pytest.raises(KeyError):
+        checkpoint.load_checkpoint(Nerf(), str(tmp_path / "bad.pth"))
