@@ -27,6 +27,14 @@ typedef _Float16 elem_t;
 #define NERF_KERNEL nerf_mlp_f16_16_kernel
 #define NERF_LAUNCH nerf_amd_launch_mlp_f16_16
 static constexpr long long IMG_OFFSET = 0;                  // the fp16 packed buffer holds only this image
+#elif defined(NERF_EXP)
+// experiment slot: built by `make EXP=1` INSTEAD of mlp_bf16.hip under that kernel's launcher
+// name, so NERF_AMD_BF16_TILE=32 selects it and tools/ab_bench.py A/Bs it against the default
+typedef __bf16 elem_t;
+#define NERF_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define NERF_KERNEL nerf_mlp_bf16_exp_kernel
+#define NERF_LAUNCH nerf_amd_launch_mlp_bf16
+static constexpr long long IMG_OFFSET = nerf_layout::B16_IMAGE_OFFSET;
 #else
 typedef __bf16 elem_t;
 #define NERF_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
@@ -126,13 +134,15 @@ struct Stage {
     static constexpr int NEXT = (CC + 1) % NUM_CHUNKS;
     static constexpr int PIECES = (chunk_kib(NEXT) + WAVES - 1) / WAVES;
     static constexpr int SRC_OFF = chunk_off_kib(NEXT) * 1024;
+    static __device__ __forceinline__ void issue_piece(const Ctx& c, int p) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+            c.wrsrc,
+            reinterpret_cast<lds_void*>(reinterpret_cast<lds_char*>(0) + c.s_wdst[NEXT & 1] + p * (WAVES * 1024)),
+            16, c.lane16, c.wave_goff + (SRC_OFF + p * WAVES * 1024), 0, 0);
+    }
     static __device__ __forceinline__ void issue(const Ctx& c) {
 #pragma unroll
-        for (int p = 0; p < PIECES; ++p)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                c.wrsrc,
-                reinterpret_cast<lds_void*>(reinterpret_cast<lds_char*>(0) + c.s_wdst[NEXT & 1] + p * (WAVES * 1024)),
-                16, c.lane16, c.wave_goff + (SRC_OFF + p * WAVES * 1024), 0, 0);
+        for (int p = 0; p < PIECES; ++p) issue_piece(c, p);
     }
 };
 
@@ -190,7 +200,9 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
     const unsigned wb = c.b_wread[CC & 1];
     const unsigned xb = D.extra_kind == 1 ? c.b_posx : c.b_posd;
 
-    Stage<CC>::issue(c);
+#if !defined(NERF_EXP) || NERF_EXP != 4
+    Stage<CC>::issue(c);            // (ablation NERF_EXP=4: no weight DMA; results are garbage)
+#endif
 
     ex8 a[AHEAD];
 #pragma unroll
@@ -251,7 +263,11 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
         st.pend[cb][0] = acc[cb][NT >= 2 ? NT - 2 : 0];
         st.pend[cb][1] = acc[cb][NT - 1];
     }
+#if defined(NERF_EXP) && NERF_EXP == 3
+    // ablation: no chunk barrier (races: results are garbage; timing only)
+#else
     __syncthreads();
+#endif
 }
 
 __host__ __device__ constexpr int prev_layer(int L, int C) { return C > 0 ? L : L - 1; }
