@@ -2,7 +2,7 @@
 // reference train.py:51-54: loss.backward() as far as the 24 parameter tensors).
 //
 //   dW_l = dY_l^T @ X_l      (sum over all P = B*N query points)
-//   db_l = sum_p dY_l[p, :]
+//   db_l = sum_p dY_l[p, :]  (accumulated from the A operand's staging registers of the same kernel)
 //
 // dY_l (from nerf_amd_mlp_backward) and X_l (the activations saved by
 // nerf_amd_mlp_forward_train, plus the encoder outputs) are [P, width] bf16
@@ -39,6 +39,7 @@ struct GemmDesc {
     int M, N;          // operand widths actually read (multiples of 32)
     int r0, Mv, Nv;    // rows [r0, r0+Mv) x cols [0, Nv) are stored
     int wg0, wgs;      // workgroups [wg0, wg0+wgs) split the K range
+    float* bias;       // non-NULL: also add the column sums of A[:, 0..M) (= db of that layer) here
 };
 struct GemmTable {
     GemmDesc d[MAXD];
@@ -65,7 +66,6 @@ __device__ __forceinline__ bf16x8 read_frag_tr(unsigned addr) {
 
 __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    (void)smem;
     // which product, which K slice
     int di = 0;
     while (di + 1 < tab.n && (int)blockIdx.x >= tab.d[di + 1].wg0) ++di;
@@ -83,6 +83,16 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
     const int srow = tid >> 5, schunk = tid & 31;
     const bool a_col = schunk * 8 < d.M, b_col = schunk * 8 < d.N;
     u32x4 ra[4], rb[4];
+    // db = column sums of dY: this thread sees 8 columns x 4 rows of A per slab in its staging registers
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto add_bias = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bf16x8 v = __builtin_bit_cast(bf16x8, ra[i]);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) bsum[k] += (float)v[k];
+        }
+    };
     auto load_slab = [&](long long s) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -121,6 +131,7 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
 
     if (s_begin < s_end) {
         load_slab(s_begin);
+        if (d.bias) add_bias();
         store_slab(0);
     }
     __syncthreads();
@@ -145,8 +156,24 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (s + 1 < s_end) store_slab(buf ^ 1);
+        if (s + 1 < s_end) {
+            if (d.bias) add_bias();
+            store_slab(buf ^ 1);
+        }
         __syncthreads();
+    }
+    if (d.bias && a_col && s_begin < s_end) {
+        // 16 threads (srow) hold partial sums of the same 8 columns: combine through LDS, then atomics
+        float* red = reinterpret_cast<float*>(smem);              // all slab reads are behind the last barrier
+#pragma unroll
+        for (int k = 0; k < 8; ++k) red[(srow * 32 + schunk) * 8 + k] = bsum[k];
+    }
+    __syncthreads();
+    if (d.bias && s_begin < s_end && tid < d.M) {
+        const int ch = tid >> 3, k = tid & 7;
+        float v = 0.f;
+        for (int r = 0; r < 16; ++r) v += reinterpret_cast<float*>(smem)[(r * 32 + ch) * 8 + k];
+        atomicAdd(d.bias + tid, v);
     }
     // split-K combine: float atomics into the flat gradient vector
     if (active && s_begin < s_end) {
@@ -161,39 +188,6 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
                     if (row >= 0 && row < d.Mv && col < d.Nv)
                         atomicAdd(d.C + (long long)row * d.ldc + col, acc[i][j][r]);
                 }
-    }
-}
-
-// ---- bias gradients: column sums of [P, width] bf16 -------------------------------
-struct ColsumTable {
-    const __bf16* src[12];
-    float* dst[12];
-    int width[12];
-    int n;
-    long long P;
-};
-__global__ __launch_bounds__(256) void colsum_kernel(ColsumTable t) {
-    __shared__ float red[256][9];
-    const int di = blockIdx.y;
-    const int W = t.width[di], groups = W / 8;          // 16-B column groups
-    const int cg = threadIdx.x % groups, rl = threadIdx.x / groups, rlanes = 256 / groups;
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const __bf16* src = t.src[di];
-    for (long long p = (long long)blockIdx.x * rlanes + rl; p < t.P; p += (long long)gridDim.x * rlanes) {
-        const bf16x8 v = *reinterpret_cast<const bf16x8*>(src + p * W + cg * 8);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s[k] += (float)v[k];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) red[threadIdx.x][k] = s[k];
-    __syncthreads();
-    if (rl == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            float a = 0.f;
-            for (int r = 0; r < rlanes; ++r) a += red[r * groups + cg][k];
-            atomicAdd(t.dst[di] + cg * 8 + k, a);
-        }
     }
 }
 
@@ -254,22 +248,24 @@ extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* a
     t.P = P;
     int n = 0;
     auto add = [&](const __bf16* A, int lda, int M, const __bf16* B, int ldb, int N, int coff, int ldc, int r0,
-                   int Mv, int Nv) {
+                   int Mv, int Nv, int boff = -1) {
         GemmDesc& g = t.d[n++];
         g.A = A; g.lda = lda; g.M = M; g.B = B; g.ldb = ldb; g.N = N;
         g.C = grads + coff; g.ldc = ldc; g.r0 = r0; g.Mv = Mv; g.Nv = Nv;
+        g.bias = boff >= 0 ? grads + boff : nullptr;      // db of the layer whose dY is this product's A
     };
     const int LW = 256 * 256 + 256;
-    add(dy(0), 256, 256, posx, 64, 64, OFF_L0_W, 63, 0, 256, 63);                         // layers_0.0
+    add(dy(0), 256, 256, posx, 64, 64, OFF_L0_W, 63, 0, 256, 63, OFF_L0_B);               // layers_0.0
     for (int l = 1; l <= 4; ++l)                                                          // layers_0.{2,4,6,8}
-        add(dy(l), 256, 256, act(l - 1), 256, 256, OFF_L1_W + (l - 1) * LW, 256, 0, 256, 256);
-    add(dy(5), 256, 256, act(4), 256, 256, OFF_SKIP_W, 319, 0, 256, 256);                 // skip [h ; x]: h part
+        add(dy(l), 256, 256, act(l - 1), 256, 256, OFF_L1_W + (l - 1) * LW, 256, 0, 256, 256,
+            OFF_L1_W + (l - 1) * LW + 65536);
+    add(dy(5), 256, 256, act(4), 256, 256, OFF_SKIP_W, 319, 0, 256, 256, OFF_SKIP_B);     // skip [h ; x]: h part
     add(dy(5), 256, 256, posx, 64, 64, OFF_SKIP_W + 256, 319, 0, 256, 63);                //               x part
-    add(dy(6), 256, 256, act(5), 256, 256, OFF_L6_W, 256, 0, 256, 256);                   // layers_1.0
-    add(dy(7), 256, 256, act(6), 256, 256, OFF_L6_W + LW, 256, 0, 256, 256);              // layers_1.2
+    add(dy(6), 256, 256, act(5), 256, 256, OFF_L6_W, 256, 0, 256, 256, OFF_L6_W + 65536); // layers_1.0
+    add(dy(7), 256, 256, act(6), 256, 256, OFF_L6_W + LW, 256, 0, 256, 256, OFF_L6_W + LW + 65536);  // layers_1.2
     add(dsr, 32, 32, act(7), 256, 256, OFF_SIG_W, 256, 3, 1, 256);                        // sigma_fc.0 (row 3 of dsr)
-    add(dy(8), 256, 256, act(7), 256, 256, OFF_L2_W, 256, 0, 256, 256);                   // layers_2
-    add(dy(9), 128, 128, act(8), 256, 256, OFF_C0_W, 283, 0, 128, 256);                   // color_fc.0 [h ; d]: h part
+    add(dy(8), 256, 256, act(7), 256, 256, OFF_L2_W, 256, 0, 256, 256, OFF_L2_B);         // layers_2
+    add(dy(9), 128, 128, act(8), 256, 256, OFF_C0_W, 283, 0, 128, 256, OFF_C0_B);         // color_fc.0 [h ; d]: h part
     add(dy(9), 128, 128, posd, 32, 32, OFF_C0_W + 256, 283, 0, 128, 27);                  //                      d part
     add(dsr, 32, 32, act(9), 128, 128, OFF_C1_W, 128, 0, 3, 128);                         // color_fc.2 (rows 0..2)
     t.n = n;
@@ -295,17 +291,5 @@ extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* a
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dw_gemm_kernel, dim3(wg), dim3(512), LDS_BYTES, stream, t);
 
-    ColsumTable c{};
-    c.P = P;
-    const int boff[10] = {OFF_L0_B, OFF_L1_W + 65536, OFF_L1_W + LW + 65536, OFF_L1_W + 2 * LW + 65536,
-                          OFF_L1_W + 3 * LW + 65536, OFF_SKIP_B, OFF_L6_W + 65536, OFF_L6_W + LW + 65536,
-                          OFF_L2_B, OFF_C0_B};
-    for (int L = 0; L < 10; ++L) {
-        c.src[L] = dy(L);
-        c.dst[L] = grads + boff[L];
-        c.width[L] = L == 9 ? 128 : 256;
-    }
-    c.n = 10;
-    hipLaunchKernelGGL(colsum_kernel, dim3(64, 10), dim3(256), 0, stream, c);
     return (int)hipGetLastError();
 }

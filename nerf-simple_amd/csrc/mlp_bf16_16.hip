@@ -47,8 +47,14 @@ typedef elem_t ex2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int WAVES = 8;
-constexpr int TILE_PTS = WAVES * 32;
+// NCB 16-point column blocks per wave: 2 (8 waves, 2 per SIMD, <= 256 registers each; default) or
+// 4 (4 waves, 1 per SIMD, accumulators in AGPRs: every weight fragment read from LDS feeds 4 MFMAs)
+#ifndef NERF_NCB
+#define NERF_NCB 2
+#endif
+constexpr int NCB = NERF_NCB;
+constexpr int WAVES = 16 / NCB;
+constexpr int TILE_PTS = WAVES * 16 * NCB;
 constexpr int TPC = 4;                        // 16-row output tiles per weight chunk (64 rows)
 
 __host__ __device__ constexpr int layer_chunks(int L) { return (b16_mt(L) + TPC - 1) / TPC; }
@@ -77,9 +83,9 @@ __host__ __device__ constexpr int chunk_off_kib(int cc) {
 constexpr int LDS_WBUF = 40 * 1024;
 constexpr int LDS_BIAS = 0;
 constexpr int LDS_W0 = 10 * 1024;
-constexpr int LDS_POSD = LDS_W0 + 2 * LDS_WBUF;               // [wave][cb][1 KiB]
-constexpr int LDS_POSX = LDS_POSD + WAVES * 2 * 1024;         // [wave][cb][2][1 KiB]
-constexpr int LDS_TOTAL = LDS_POSX + WAVES * 4 * 1024;
+constexpr int LDS_POSD = LDS_W0 + 2 * LDS_WBUF;
+constexpr int LDS_POSX = LDS_POSD + WAVES * NCB * 1024;
+constexpr int LDS_TOTAL = LDS_POSX + WAVES * NCB * 2048;
 static_assert(B16_BIAS_FLOATS * 4 <= LDS_W0, "bias table");
 static_assert(LDS_TOTAL <= 160 * 1024 && NUM_CHUNKS % 2 == 0, "LDS budget / parity");
 
@@ -107,13 +113,13 @@ struct Ctx {
 };
 
 struct State {
-    ex8 X[2][8], Y[2][8];        // [column block][k-step of 32]
-    f32x4 pend[2][2];               // [column block][tile of the pending pair]
-    float sigma[2], rgb[2][3];
+    ex8 X[NCB][8], Y[NCB][8];        // [column block][k-step of 32]
+    f32x4 pend[NCB][2];               // [column block][tile of the pending pair]
+    float sigma[NCB], rgb[NCB][3];
     // training forward only (SAVE): where this lane's activations go
     char* acts;
     long long P;
-    long long prow[2];              // point index of column block cb, -1 past the end
+    long long prow[NCB];              // point index of column block cb, -1 past the end
     int goff;                       // (lane>>4) * 8 bytes
 };
 
@@ -151,9 +157,9 @@ struct Stage {
 // next layer's fragment Q.  Heads: (L8, Q=8) is the lone sigma tile, L10 the
 // rgb tile.
 template <int L, int Q, bool SAVE = false>
-__device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], ex8 (&dst)[2][8], State& st) {
+__device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2], ex8 (&dst)[NCB][8], State& st) {
     constexpr LayerDesc D = layer_desc(L);
-    const int cb = i >> 2, j2 = i & 3;
+    const int cb = i >> 2, j2 = i & 3;   // i in [0, 4*NCB)
     if constexpr (L == 10) {
         if (j2 == 0) { st.rgb[cb][0] = acc[cb][0][0]; st.rgb[cb][1] = acc[cb][0][1]; st.rgb[cb][2] = acc[cb][0][2]; }
     } else if constexpr (L == 8 && Q == 8) {
@@ -177,7 +183,7 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
 // ---- one chunk: NT 16-row tiles of layer L starting at tile 4C -------------------
 // PL/PQ: layer / pair of the pending accumulators handed over by the previous chunk.
 template <int L, int C, int PL, int PQ, bool SAVE>
-__device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8]) {
+__device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NCB][8], ex8 (&out)[NCB][8]) {
     constexpr LayerDesc D = layer_desc(L);
     constexpr int KS_CHAIN = D.chain_k / 32;
     constexpr int KS_EXTRA = D.extra_slots / 32;
@@ -190,12 +196,12 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
     constexpr int BIAS_OFF = LDS_BIAS + (b16_bias_off(L) + 16 * RT0) * 4;
     constexpr int XBLK = D.extra_kind == 1 ? 2048 : 1024;
     // chunk-linear MFMA index m = (t*KS + ks)*2 + cb
-    constexpr int MT = 2 * KS;                      // MFMAs per row tile
-    constexpr int PEND_M0 = (L == 10) ? 0 : (NT * MT >= 12 ? 2 : 0);
+    constexpr int MT = NCB * KS;                      // MFMAs per row tile
+    constexpr int PEND_M0 = (L == 10) ? 0 : (NT * MT >= 4 * NCB + 4 ? 2 : 0);
     constexpr int PEND_PER = (L == 10) ? 2 : 1;     // pieces per MFMA for the pending pair
-    constexpr int PAIR_M0 = 2 * MT + (MT >= 10 ? 2 : 0);
+    constexpr int PAIR_M0 = 2 * MT + (MT >= 4 * NCB + 2 ? 2 : 0);
     // a pending pair of the PREVIOUS layer is this layer's k-step PQ, first read by MFMA 2*PQ
-    static_assert(PL < 0 || PL == L || (PL == 8 && PQ == 8) || 2 * PQ >= PEND_M0 + 8 / PEND_PER,
+    static_assert(PL < 0 || PL == L || (PL == 8 && PQ == 8) || NCB * PQ >= PEND_M0 + 4 * NCB / PEND_PER,
                   "pending pair finished too late");
     const unsigned wb = c.b_wread[CC & 1];
     const unsigned xb = D.extra_kind == 1 ? c.b_posx : c.b_posd;
@@ -207,17 +213,17 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
     ex8 a[AHEAD];
 #pragma unroll
     for (int f = 0; f < AHEAD && f < F; ++f) a[f] = lds_load<ex8>(wb, f * 1024);
-    ex8 bx[2][KS_EXTRA > 0 ? KS_EXTRA : 1];
+    ex8 bx[NCB][KS_EXTRA > 0 ? KS_EXTRA : 1];
     if constexpr (KS_EXTRA > 0) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
             for (int e = 0; e < KS_EXTRA; ++e) bx[cb][e] = lds_load<ex8>(xb, cb * XBLK + e * 1024);
     }
-    f32x4 acc[2][NT];
+    f32x4 acc[NCB][NT];
     // register i of lane group g is row 16*rt + 4g + i: one 16-B bias read per tile
     acc[0][0] = lds_load<f32x4>(c.b_bias, BIAS_OFF);
-    acc[1][0] = acc[0][0];
+    for (int cb = 1; cb < NCB; ++cb) acc[cb][0] = acc[0][0];
     __builtin_amdgcn_sched_barrier(0);
 
 #pragma unroll
@@ -229,19 +235,19 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
             if (f + AHEAD < F) a[f % AHEAD] = lds_load<ex8>(wb, (f + AHEAD) * 1024);
             if (t + 1 < NT && ks == KS / 2) {
                 acc[0][t + 1 < NT ? t + 1 : 0] = lds_load<f32x4>(c.b_bias, BIAS_OFF + 64 * (t + 1));
-                acc[1][t + 1 < NT ? t + 1 : 0] = acc[0][t + 1 < NT ? t + 1 : 0];
+                for (int cb = 1; cb < NCB; ++cb) acc[cb][t + 1 < NT ? t + 1 : 0] = acc[0][t + 1 < NT ? t + 1 : 0];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int m = f * 2 + cb;
+            for (int cb = 0; cb < NCB; ++cb) {
+                const int m = f * NCB + cb;
                 ex8 bs;
                 if (ks < KS_CHAIN) bs = in[cb][ks < KS_CHAIN ? ks : 0];
                 else bs = bx[cb][KS_EXTRA > 0 ? (ks - KS_CHAIN < KS_EXTRA ? ks - KS_CHAIN : 0) : 0];
                 acc[cb][t] = NERF_MFMA(as, bs, acc[cb][t], 0, 0, 0);
                 // ---- epilogue pieces in this MFMA's shadow
                 if constexpr (PL >= 0) {
-                    if (m >= PEND_M0 && m < PEND_M0 + 8 / PEND_PER) {
+                    if (m >= PEND_M0 && m < PEND_M0 + 4 * NCB / PEND_PER) {
 #pragma unroll
                         for (int k = 0; k < PEND_PER; ++k) {
                             const int i = (m - PEND_M0) * PEND_PER + k;
@@ -250,8 +256,9 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
                         }
                     }
                 }
-                if (NT == 4 && m >= PAIR_M0 && m < PAIR_M0 + 8) {
-                    const f32x4 pr[2][2] = {{acc[0][0], acc[0][NT > 1 ? 1 : 0]}, {acc[1][0], acc[1][NT > 1 ? 1 : 0]}};
+                if (NT == 4 && m >= PAIR_M0 && m < PAIR_M0 + 4 * NCB) {
+                    f32x4 pr[NCB][2];
+                    for (int q_ = 0; q_ < NCB; ++q_) { pr[q_][0] = acc[q_][0]; pr[q_][1] = acc[q_][NT > 1 ? 1 : 0]; }
                     epilogue_piece<L, 2 * C, SAVE>(m - PAIR_M0, pr, out, st);
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -259,7 +266,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
         }
     }
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
         st.pend[cb][0] = acc[cb][NT >= 2 ? NT - 2 : 0];
         st.pend[cb][1] = acc[cb][NT - 1];
     }
@@ -278,12 +285,12 @@ __host__ __device__ constexpr int prev_pair(int L, int C) {
 }
 
 template <int L, bool SAVE, int... Cs>
-__device__ __forceinline__ void run_layer_seq(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8],
+__device__ __forceinline__ void run_layer_seq(const Ctx& c, State& st, ex8 (&in)[NCB][8], ex8 (&out)[NCB][8],
                                               std::integer_sequence<int, Cs...>) {
     (chunk_step<L, Cs, prev_layer(L, Cs), prev_pair(L, Cs), SAVE>(c, st, in, out), ...);
 }
 template <int L, bool SAVE>
-__device__ __forceinline__ void run_layer(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8]) {
+__device__ __forceinline__ void run_layer(const Ctx& c, State& st, ex8 (&in)[NCB][8], ex8 (&out)[NCB][8]) {
     run_layer_seq<L, SAVE>(c, st, in, out, std::make_integer_sequence<int, layer_chunks(L)>{});
 }
 
@@ -298,8 +305,8 @@ template <bool RAYS>
 __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base, State& st) {
     const int col = c.lane & 15, g = c.lane >> 4;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        long long p = tile_base + c.wave * 32 + cb * 16 + col;
+    for (int cb = 0; cb < NCB; ++cb) {
+        long long p = tile_base + c.wave * (16 * NCB) + cb * 16 + col;
         const bool valid = p < a.P;
         st.prow[cb] = valid ? p : -1;
         if (!valid) p = a.P - 1;
@@ -364,8 +371,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
         c.s_wdst[p] = LDS_W0 + p * LDS_WBUF + c.wave * 1024;
     }
     c.b_bias = (c.lane >> 4) * 16;
-    c.b_posx = LDS_POSX + c.wave * 4096 + c.lane * 16;
-    c.b_posd = LDS_POSD + c.wave * 2048 + c.lane * 16;
+    c.b_posx = LDS_POSX + c.wave * (NCB * 2048) + c.lane * 16;
+    c.b_posd = LDS_POSD + c.wave * (NCB * 1024) + c.lane * 16;
 
     {
         const float* bsrc = reinterpret_cast<const float*>(img + (long long)B16_WEIGHT_KIB * 1024);
@@ -396,12 +403,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
         run_layer<9, SAVE>(c, st, st.X, st.Y);
         run_layer<10, SAVE>(c, st, st.Y, st.X);
         epilogue_piece<10, 0>(0, st.pend, st.X, st);     // the rgb tile is still pending
-        epilogue_piece<10, 0>(4, st.pend, st.X, st);
+        for (int cb_ = 1; cb_ < NCB; ++cb_) epilogue_piece<10, 0>(4 * cb_, st.pend, st.X, st);
 
         if (c.lane < 16) {
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const long long p = tile_base + c.wave * 32 + cb * 16 + c.lane;
+            for (int cb = 0; cb < NCB; ++cb) {
+                const long long p = tile_base + c.wave * (16 * NCB) + cb * 16 + c.lane;
                 if (p < a.P) {
                     const f32x4 o = {st.rgb[cb][0], st.rgb[cb][1], st.rgb[cb][2], st.sigma[cb]};
                     *reinterpret_cast<f32x4*>(a.raw + p * 4) = o;
