@@ -202,6 +202,15 @@ int nerf_amd_param_gradients(const float* d_raw, const void* acts, const void* d
                              const void* posx64, const void* posd32, void* scratch,
                              float* grads, int64_t P, void* stream);
 
+/* ---- optimizer: torch.optim.Adam defaults, reference train.py:43,55 ------------- */
+/* One launch over the flat fp32 parameter vector (state_dict order; the 24 tensors are
+ * views of it): params, exp_avg, exp_avg_sq updated in place from grads; `step` >= 1 is
+ * the 1-based step count used for the bias corrections.  No amsgrad / weight decay, as
+ * in the reference.  Follow with nerf_amd_pack_weights on `params`. */
+int nerf_amd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                       int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

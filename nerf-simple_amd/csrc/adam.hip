@@ -1,0 +1,38 @@
+// adam.hip -- the optimizer step of the training loop (reference train.py:43,55-57:
+// torch.optim.Adam(lr=5e-4, betas=(0.9,0.999), eps=1e-8) + per-step exponential LR
+// decay) as ONE kernel over the flat fp32 parameter vector (state_dict order),
+// SURVEY.md section 8f, N3.  The 24 tensors are views of that vector on the Python
+// side, so there is no per-tensor launch; the packed MFMA weight images are
+// re-derived from the same vector right after (nerf_amd_pack_weights).
+//
+// Per element, exactly torch's single-tensor Adam (no amsgrad, no weight decay):
+//   m = b1 m + (1-b1) g ;  v = b2 v + (1-b2) g^2
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#include "nerf_device.h"
+
+namespace {
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                            float bc1, float bc2_sqrt) {
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+}  // namespace
+
+extern "C" int nerf_amd_launch_adam(float* params, const float* grads, float* m, float* v, long long n, float lr,
+                                    float b1, float b2, float eps, float bc1, float bc2_sqrt, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n == 0) return 0;
+    long long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)grid), dim3(256), 0, stream, params, grads, m, v, n, lr, b1, b2,
+                       eps, bc1, bc2_sqrt);
+    return (int)hipGetLastError();
+}

@@ -4,6 +4,7 @@
 #include "nerf_device.h"
 #include "../../include/nerf_amd.h"
 #include <stdlib.h>
+#include <math.h>
 
 #ifndef NERF_AMD_DEFAULT_BF16_TILE
 #define NERF_AMD_DEFAULT_BF16_TILE 16
@@ -29,6 +30,8 @@ int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, long long, hipStream_t);
+int nerf_amd_launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float, float,
+                         hipStream_t);
 int nerf_amd_launch_sample_encode_bf16(const MlpArgs*, void*, void*, hipStream_t);
 int nerf_amd_launch_param_gradients(const float*, const void*, const void*, const void*, const void*, void*, float*,
                                     long long, hipStream_t);
@@ -338,6 +341,18 @@ int nerf_amd_param_gradients(const float* d_raw, const void* acts, const void* d
     if (P < 0 || !grads) return NERF_AMD_EINVAL;
     if (P > 0 && (!d_raw || !acts || !dys || !posx64 || !posd32 || !scratch)) return NERF_AMD_EINVAL;
     return nerf_amd_launch_param_gradients(d_raw, acts, dys, posx64, posd32, scratch, grads, P, S(stream));
+}
+
+int nerf_amd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       float lr, float beta1, float beta2, float eps, int64_t step, void* stream) {
+    if (n < 0 || step < 1) return NERF_AMD_EINVAL;
+    if (n == 0) return 0;
+    if (!params || !grads || !exp_avg || !exp_avg_sq) return NERF_AMD_EINVAL;
+    // bias corrections in double on the host, as torch does for a python-number step
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    return nerf_amd_launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1,
+                                (float)sqrt(bc2), S(stream));
 }
 
 }  // extern "C"

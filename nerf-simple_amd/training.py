@@ -220,7 +220,7 @@ def train_step(net, optimizer, rays, gt, N, *, tn=2, tf=6, u=None, decay=1.0, gr
     Only ``rgb`` feeds the loss, as in the reference (train.py:52)."""
     from . import parallel
     from .utils.rendering import render_nerf
-    optimizer.zero_grad(set_to_none=False)
+    optimizer.zero_grad(set_to_none=True)
     rgb, _, _, _, _ = render_nerf(rays, net, N, tn, tf, u=u, precision=precision,
                                   device_rng=device_rng, seed=seed, ray_id0=ray_id0)
     loss = F.mse_loss(rgb, gt)

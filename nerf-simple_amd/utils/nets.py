@@ -86,6 +86,23 @@ class Nerf(nn.Module):
         self._packed[key] = (stamp, packed)
         return packed
 
+    def repack_from_flat(self, flat):
+        """Re-derive every packed image already in use from a flat fp32 parameter
+        vector (state_dict order) whose views ARE this module's parameters
+        (optim.FusedAdam): no per-tensor concatenation, cache stays valid."""
+        lib = _lib.lib()
+        dev = flat.device
+        stamp = tuple((p.data_ptr(), p._version) for p in self._param_list())
+        codes = {code for (d, code) in self._packed if d == dev} or {_lib.precision_code(self.precision)}
+        with torch.cuda.device(dev):
+            for code in codes:
+                hit = self._packed.get((dev, code))
+                packed = hit[1] if hit is not None else torch.empty(
+                    lib.nerf_amd_packed_bytes(code), dtype=torch.uint8, device=dev)
+                _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(flat), _lib.ptr(packed), code,
+                                                     _lib.stream_ptr(dev)), "nerf_amd_pack_weights")
+                self._packed[(dev, code)] = (stamp, packed)
+
     # ---- forward ---------------------------------------------------------------
     def forward(self, v, *, precision=None):
         _lib.require_cuda_f32(v, "v")

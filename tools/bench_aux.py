@@ -63,12 +63,14 @@ with torch.no_grad():
         print(json.dumps({"config": "4: 800x800 hierarchical 64 + (64+128) bf16, 1 GPU", "ms": dt * 1e3,
                           "mlp_evals_per_s": s / dt, "tflops": s * FLOP / dt / 1e12}))
 if "c5" in which:          # config 5: training steps, 4096 rays x {64,128}, bf16
-    for N in (64, 128):
+    from nerf_simple_amd.optim import FusedAdam
+    for N, fused_opt in ((64, True), (128, True), (64, False)):
         net = net_of("bf16")
-        opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+        opt = FusedAdam(net, lr=5e-4) if fused_opt else torch.optim.Adam(net.parameters(), lr=5e-4)
         rays = generate_rays(pose, [800, 800, synthetic.focal_from_fov(800)], dev)[:4096].contiguous()
         gt = torch.rand(4096, 3, device=dev)
         dt = timed(lambda: train_step(net, opt, rays, gt, N, device_rng=True, seed=1), warm=3, reps=10)
         s = 4096 * N
-        print(json.dumps({"config": f"5: train step 4096 rays x {N} bf16 (fwd+bwd+Adam)", "ms": dt * 1e3,
+        print(json.dumps({"config": f"5: train step 4096 rays x {N} bf16 (fwd+bwd+" +
+                          ("FusedAdam+repack)" if fused_opt else "torch Adam)"), "ms": dt * 1e3,
                           "ray_samples_per_s": s / dt, "tflops_fwd_bwd(3x)": 3 * s * FLOP / dt / 1e12}))
