@@ -62,6 +62,16 @@ with torch.no_grad():
         s = 800 * 800 * (64 + 192)
         print(json.dumps({"config": "4: 800x800 hierarchical 64 + (64+128) bf16, 1 GPU", "ms": dt * 1e3,
                           "mlp_evals_per_s": s / dt, "tflops": s * FLOP / dt / 1e12}))
+if "pcie" in which:        # reference-compatible jitter: one CPU torch.rand(B,N) per call + H2D copy
+    from nerf_simple_amd.utils.rendering import render_nerf
+    with torch.no_grad():
+        net = net_of("bf16")
+        rays = generate_rays(pose, [800, 800, synthetic.focal_from_fov(800)], dev)
+        for B in (16000, 640000):
+            r = rays[:B].contiguous()
+            dt = timed(lambda: render_nerf(r, net, 128, outputs=("rgb", "disp", "acc")), warm=1, reps=3)
+            print(json.dumps({"config": f"3 (parity mode): render_nerf B={B} N=128, jitter drawn on the CPU + PCIe copy",
+                              "ms": dt * 1e3, "ray_samples_per_s": B * 128 / dt}))
 if "c5" in which:          # config 5: training steps, 4096 rays x {64,128}, bf16
     from nerf_simple_amd.optim import FusedAdam
     for N, fused_opt in ((64, True), (128, True), (64, False)):
