@@ -12,8 +12,11 @@
 //   * ONE launch covers all 14 products; each gets a share of the ~256
 //     workgroups proportional to the bytes it streams (split-K over the points);
 //   * a workgroup (8 waves) owns the full 256x256 output of its product in
-//     registers and walks its K slice in slabs of 64 points, staged
-//     HBM -> registers -> LDS (row-major, rows padded to 576 B), double buffered;
+//     registers and walks its K slice in slabs of 32 points, moved HBM -> LDS by
+//     LDS-DMA (no staging registers) into a 4-slot ring: three slabs (96 KiB per
+//     CU) stay in flight behind counted vmcnt waits and one raw s_barrier per slab;
+//   * the LDS image is row-major and unpadded with an XOR swizzle of the 16-byte
+//     chunks (applied to the DMA's per-lane source and to the reads);
 //   * fragments come out of LDS through ds_read_b64_tr_b16, the hardware
 //     transposing read: 4 points x 16 features in, 4 consecutive k per lane out,
 //     so no transpose pass exists anywhere;
@@ -47,21 +50,40 @@ struct GemmTable {
     long long P;
 };
 
-constexpr int SLAB = 64;                       // points per LDS slab (4 k-steps of 16)
-constexpr int ROWB = 576;                      // LDS row stride: 512 B of features + 64 B
-                                               // (rows 16 banks apart: conflict-free tr reads)
-constexpr int OPB = SLAB * ROWB;               // one operand slab = 36 KiB
-constexpr int LDS_BYTES = 4 * OPB;             // {A,B} x 2 buffers = 144 KiB
+constexpr int SLAB = 32;                       // points per LDS slab (2 k-steps of 16)
+static_assert(SLAB == 32, "the slab loop is written for two k-steps");
+constexpr int ROWB = 512;                      // LDS row = 256 bf16 features, unpadded (LDS-DMA is lane-linear)
+constexpr int OPB = SLAB * ROWB;               // one operand slab = 16 KiB
+constexpr int SLOTB = 2 * OPB;                 // A + B
+constexpr int RING = 4;                        // slabs resident in LDS: one computing, up to three landing
+constexpr int LDS_BYTES = RING * SLOTB;        // 128 KiB
+constexpr int DMA_PER_SLAB = 2 * SLAB / 2 / 8; // 1 KiB wave-instructions per wave per slab (8 waves) = 4
 
 typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) void lds_void;
 
-__device__ __forceinline__ bf16x8 read_frag_tr(unsigned addr) {
-    // two transposing reads: k = 8h + 0..3 and 8h + 4..7 of this lane's column
-    const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-        reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(reinterpret_cast<lds_char*>(0) + addr));
-    const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-        reinterpret_cast<__attribute__((address_space(3))) bf16x4*>(reinterpret_cast<lds_char*>(0) + addr + 4 * ROWB));
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+// LDS image: row r (a point) holds its 32 16-byte chunks at positions chunk ^ ((r & 3) << 2).
+// The LDS-DMA destination is lane-linear, so the swizzle is applied to each lane's SOURCE chunk
+// and again to the read address (cdna_hip_programming.md section 5.4 rule 21).  With it the 8
+// (row, 32-byte) pieces a half-wave touches in one ds_read_b64_tr_b16 fall in 8 distinct
+// 32-byte slots of the 256-byte bank row: conflict-free without padding.
+// The transposing reads are issued through inline asm: hipcc treats the ds_read_tr builtin as a
+// possible alias of every LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of it, which
+// would drain the three-slab prefetch each slab.  The asm reads are invisible to the compiler's
+// counters, so their lgkmcnt wait is explicit too (frags_landed ties the registers to the wait).
+struct Frag { bf16x4 lo, hi; };                    // k = 8h + 0..3 and 8h + 4..7 of this lane's column
+__device__ __forceinline__ void read_frag_tr(Frag& f, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048"
+                 : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr));
+}
+static_assert(4 * ROWB == 2048, "second transposing read is 4 rows further");
+__device__ __forceinline__ void frags_landed(Frag (&a)[4], Frag (&b)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0].lo), "+v"(a[0].hi), "+v"(a[1].lo), "+v"(a[1].hi), "+v"(a[2].lo), "+v"(a[2].hi),
+                   "+v"(a[3].lo), "+v"(a[3].hi), "+v"(b[0].lo), "+v"(b[0].hi), "+v"(b[1].lo), "+v"(b[1].hi));
+}
+__device__ __forceinline__ bf16x8 whole(const Frag& f) {
+    return bf16x8{f.lo[0], f.lo[1], f.lo[2], f.lo[3], f.hi[0], f.hi[1], f.hi[2], f.hi[3]};
 }
 
 __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
@@ -79,45 +101,51 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
     const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves over the 256 x 256 tile
     const int m0 = 128 * wm, n0 = 64 * wn;            // this wave: 4 x 2 tiles of 32 x 32
 
-    // staging geometry: thread -> (row tid>>5 + 16 i, 16-B chunk tid&31) of a slab, i = 0..3
-    const int srow = tid >> 5, schunk = tid & 31;
-    const bool a_col = schunk * 8 < d.M, b_col = schunk * 8 < d.N;
-    u32x4 ra[4], rb[4];
-    // db = column sums of dY: this thread sees 8 columns x 4 rows of A per slab in its staging registers
-    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto add_bias = [&]() {
+    // ---- LDS-DMA geometry: wave w issues pieces 4w .. 4w+3 of a slab; piece i = operand i>>4,
+    // row pair i&15; lane l lands at row 2(i&15) + (l>>5), chunk position l&31
+    // The descriptors are rebased to this workgroup's K slice and end at min(P, slice end): rows
+    // past the operand return zeros through the VGPR-offset range check (the SGPR offset is not
+    // range-checked on gfx9-family raw buffers, so the slab offset travels in the VGPR).
+    const long long row_begin = s_begin * SLAB;
+    const long long row_end = s_end * SLAB < tab.P ? s_end * SLAB : tab.P;
+    const long long slice_rows = row_end > row_begin ? row_end - row_begin : 0;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(d.A + row_begin * d.lda), 0, (int)(slice_rows * d.lda * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(d.B + row_begin * d.ldb), 0, (int)(slice_rows * d.ldb * 2), 0x00020000);
+    constexpr unsigned OUTSIDE = 0xffffffffu;         // >= num_records: the lane loads zeros
+    unsigned voff[DMA_PER_SLAB];                      // per-lane source offset inside a slab
+    unsigned ldst[DMA_PER_SLAB];                      // wave-uniform destination inside a ring slot
+    const bool pieceA = wave < 4;                     // pieces 0..15 are A, 16..31 are B
+    const int pld = pieceA ? d.lda : d.ldb;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bf16x8 v = __builtin_bit_cast(bf16x8, ra[i]);
+    for (int k = 0; k < DMA_PER_SLAB; ++k) {
+        const int piece = wave * DMA_PER_SLAB + k, rowpair = piece & 15;
+        const int row = 2 * rowpair + (lane >> 5);
+        const int cg = (lane & 31) ^ ((row & 3) << 2);                    // the global chunk this LDS position holds
+        const int width = pieceA ? d.M : d.N;
+        voff[k] = cg * 8 < width ? (unsigned)(row * pld * 2 + cg * 16) : OUTSIDE;
+        ldst[k] = (piece >> 4) * OPB + rowpair * 1024;
+    }
+    auto issue_slab = [&](int it, int slot) {         // it = slab index inside the slice
+        const unsigned slab_off = (unsigned)it * (unsigned)(SLAB * pld * 2);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) bsum[k] += (float)v[k];
+        for (int k = 0; k < DMA_PER_SLAB; ++k) {
+            lds_void* dst = reinterpret_cast<lds_void*>(reinterpret_cast<lds_char*>(0) + slot * SLOTB + ldst[k]);
+            const unsigned off = voff[k] == OUTSIDE ? OUTSIDE : voff[k] + slab_off;
+            if (pieceA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, off, 0, 0, 0);
+            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, off, 0, 0, 0);
         }
     };
-    auto load_slab = [&](long long s) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long long p = s * SLAB + srow + 16 * i;
-            ra[i] = u32x4{0u, 0u, 0u, 0u};
-            rb[i] = u32x4{0u, 0u, 0u, 0u};
-            if (p < tab.P) {
-                if (a_col) ra[i] = *reinterpret_cast<const u32x4*>(d.A + p * d.lda + schunk * 8);
-                if (b_col) rb[i] = *reinterpret_cast<const u32x4*>(d.B + p * d.ldb + schunk * 8);
-            }
-        }
-    };
-    auto store_slab = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned off = (srow + 16 * i) * ROWB + schunk * 16;
-            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(
-                reinterpret_cast<lds_char*>(0) + buf * 2 * OPB + off) = ra[i];
-            *reinterpret_cast<__attribute__((address_space(3))) u32x4*>(
-                reinterpret_cast<lds_char*>(0) + buf * 2 * OPB + OPB + off) = rb[i];
-        }
-    };
-    // fragment address of this lane inside a slab: row (8h + q), column 16 (group&1) + 4p
+
+    // ---- fragment addresses: row (8h + q), logical chunk 4*tile + 2(group&1) + (p>>1), swizzled by q
     const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = lane >> 5;
-    const unsigned frag_off = (8 * h + q) * ROWB + (16 * (grp & 1) + 4 * pp) * 2;
+    const unsigned lane_off = (8 * h + q) * ROWB + (2 * (grp & 1) + (pp >> 1)) * 16 + 8 * (pp & 1);
+    unsigned aoff[4], boff[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aoff[i] = lane_off + (((m0 / 32 + i) ^ q) << 6);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) boff[j] = OPB + lane_off + (((n0 / 32 + j) ^ q) << 6);
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -128,45 +156,67 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // waves whose tile rows / columns lie outside the product skip the arithmetic
     const bool active = m0 < d.M && n0 < d.N;
+    // db = column sums of dY (the A operand): thread -> logical chunk tid&31, rows (tid>>5) + 16 i
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int brow = tid >> 5, bchunk = tid & 31;
 
-    if (s_begin < s_end) {
-        load_slab(s_begin);
-        if (d.bias) add_bias();
-        store_slab(0);
-    }
-    __syncthreads();
+    // prologue: up to RING-1 slabs in flight
+#pragma unroll
+    for (int k = 0; k < RING - 1; ++k)
+        if (s_begin + k < s_end) issue_slab(k, k);
     for (long long s = s_begin; s < s_end; ++s) {
-        const int buf = (int)((s - s_begin) & 1);
-        if (s + 1 < s_end) load_slab(s + 1);
+        const int it = (int)(s - s_begin), slot = it & (RING - 1);
+        // this wave's pieces of slab s have landed once at most the DMAs of the (up to) two newer slabs remain
+        const long long left = s_end - s;
+        if (left >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (left == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // everyone's pieces landed; everyone is done with slab s-1
+        if (s + RING - 1 < s_end) issue_slab(it + RING - 1, (it + RING - 1) & (RING - 1));
+        const unsigned base = slot * SLOTB;
         if (active) {
-            const unsigned abase = buf * 2 * OPB + frag_off, bbase = abase + OPB;
+            // two k-steps per slab: the second step's fragments are read under the first step's MFMAs
+            Frag a0[4], b0[2], a1[4], b1[2];
 #pragma unroll
-            for (int ks = 0; ks < SLAB / 16; ++ks) {
-                bf16x8 af[4], bf[2];
+            for (int i = 0; i < 4; ++i) read_frag_tr(a0[i], base + aoff[i]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    af[i] = read_frag_tr(abase + ks * 16 * ROWB + (m0 + 32 * i) * 2);
+            for (int j = 0; j < 2; ++j) read_frag_tr(b0[j], base + boff[j]);
+            frags_landed(a0, b0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) read_frag_tr(a1[i], base + aoff[i] + 16 * ROWB);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) read_frag_tr(b1[j], base + boff[j] + 16 * ROWB);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    bf[j] = read_frag_tr(bbase + ks * 16 * ROWB + (n0 + 32 * j) * 2);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whole(a0[i]), whole(b0[j]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            frags_landed(a1, b1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whole(a1[i]), whole(b1[j]), acc[i][j], 0, 0, 0);
+        }
+        if (d.bias && bchunk * 8 < d.M) {
+#pragma unroll
+            for (int i = 0; i < SLAB / 16; ++i) {
+                const int r = brow + 16 * i;
+                const bf16x8 v = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(
+                    reinterpret_cast<lds_char*>(0) + base + r * ROWB + ((bchunk ^ ((r & 3) << 2)) << 4));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) bsum[k] += (float)v[k];
             }
         }
-        if (s + 1 < s_end) {
-            if (d.bias) add_bias();
-            store_slab(buf ^ 1);
-        }
-        __syncthreads();
     }
-    if (d.bias && a_col && s_begin < s_end) {
-        // 16 threads (srow) hold partial sums of the same 8 columns: combine through LDS, then atomics
-        float* red = reinterpret_cast<float*>(smem);              // all slab reads are behind the last barrier
+    __syncthreads();
+    if (d.bias && bchunk * 8 < d.M && s_begin < s_end) {
+        // 16 threads (brow) hold partial sums of the same 8 columns: combine through LDS, then atomics
+        float* red = reinterpret_cast<float*>(smem);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) red[(srow * 32 + schunk) * 8 + k] = bsum[k];
+        for (int k = 0; k < 8; ++k) red[(brow * 32 + bchunk) * 8 + k] = bsum[k];
     }
     __syncthreads();
     if (d.bias && s_begin < s_end && tid < d.M) {
@@ -269,22 +319,44 @@ extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* a
     add(dy(9), 128, 128, posd, 32, 32, OFF_C0_W + 256, 283, 0, 128, 27);                  //                      d part
     add(dsr, 32, 32, act(9), 128, 128, OFF_C1_W, 128, 0, 3, 128);                         // color_fc.2 (rows 0..2)
     t.n = n;
-    // workgroups per product, about one per CU in total.  The kernel is HBM-bound, so a product's
-    // cost per slab is the bytes it streams, (M + N) * 2 per point, not its M*N flops (sizing by
-    // flops left the thin products -- 32 x 256 reads as much of X as 256 x 256 -- as a 2 ms tail)
+    // workgroups per product, one per CU in total.  A slab costs a workgroup the bytes it streams,
+    // (M + N) * 2 per point, plus a fixed part (barrier, DMA issue, fragment reads) that measures
+    // larger than the byte part: profiles/r01e_dw_sweep.jsonl -- weights (M + N) + c with c = 0 /
+    // 256 / 1024 / 8192 give 0.79 / 0.63 / 0.62 / 0.61 ms at 262144 points.  (Sizing by flops
+    // left the thin products -- 32 x 256 reads as much of X as 256 x 256 -- as a 2 ms tail.)
+    constexpr double slab_cost = 1024.0;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     double total = 0;
-    for (int i = 0; i < n; ++i) total += (double)(t.d[i].M + t.d[i].N);
+    for (int i = 0; i < n; ++i) total += (double)(t.d[i].M + t.d[i].N) + slab_cost;
     const long long nslab = (P + SLAB - 1) / SLAB;
+    // exactly `cus` workgroups in total when the slices allow it (the 128 KiB ring leaves one
+    // workgroup per CU, so a 257th would run as a second wave and double the kernel's time):
+    // floor of each share, then the largest remainders get the leftover workgroups
+    const long long need = (P * 512 >> 30) + 1;           // a slice's operand stays below 1 GiB (32-bit buffer range)
+    long long w[16];
+    double rem[16];
+    long long used = 0;
+    for (int i = 0; i < n; ++i) {
+        const double share = ((double)(t.d[i].M + t.d[i].N) + slab_cost) / total * cus;
+        w[i] = (long long)share;
+        rem[i] = share - (double)w[i];
+        if (w[i] < need) { w[i] = need; rem[i] = 0; }
+        if (w[i] >= nslab) { w[i] = nslab; rem[i] = -1; }
+        used += w[i];
+    }
+    while (used < cus) {
+        int best = -1;
+        for (int i = 0; i < n; ++i)
+            if (rem[i] >= 0 && w[i] < nslab && (best < 0 || rem[i] > rem[best])) best = i;
+        if (best < 0) break;
+        ++w[best]; rem[best] = 0; ++used;      // a second round goes by product order
+    }
     int wg = 0;
     for (int i = 0; i < n; ++i) {
-        long long w = (long long)((double)(t.d[i].M + t.d[i].N) / total * cus + 0.5);
-        if (w < 1) w = 1;
-        if (w > nslab) w = nslab;
         t.d[i].wg0 = wg;
-        t.d[i].wgs = (int)w;
-        wg += (int)w;
+        t.d[i].wgs = (int)w[i];
+        wg += (int)w[i];
     }
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(dw_gemm_kernel),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

@@ -253,6 +253,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, bf16x8 (&in)
         }
     }
     st.pend = acc[NT - 1];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
     __syncthreads();
 }
 
@@ -370,6 +371,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bf16_kernel(Ml
             lds_store<float>(i * 4, LDS_BIAS, bsrc[i]);
         Stage<NUM_CHUNKS - 1>::issue(c);         // NEXT == chunk 0
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
     __syncthreads();
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

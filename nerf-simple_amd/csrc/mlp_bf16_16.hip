@@ -273,6 +273,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
 #if defined(NERF_EXP) && NERF_EXP == 3
     // ablation: no chunk barrier (races: results are garbage; timing only)
 #else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
     __syncthreads();
 #endif
 }
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
             lds_store<float>(i * 4, LDS_BIAS, bsrc[i]);
         Stage<NUM_CHUNKS - 1>::issue(c);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
     __syncthreads();
 
     for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

@@ -231,6 +231,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
         st.pmask[cb][0] = m1[cb][0];
         st.pmask[cb][1] = m1[cb][1];
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
     __syncthreads();
 }
 
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(Bwd
         c.s_wdst[p] = LDS_W0 + p * LDS_WBUF + c.wave * 1024;
     }
     Stage<NUM_CHUNKS - 1>::issue(c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
     __syncthreads();
 
     const int col = c.lane & 15, g = c.lane >> 4;
