@@ -119,8 +119,12 @@ struct State {
     // training forward only (SAVE): where this lane's activations go
     char* acts;
     long long P;
-    long long prow[NCB];              // point index of column block cb, -1 past the end
-    int goff;                       // (lane>>4) * 8 bytes
+    long long tile_base;              // first point of the tile (uniform)
+    int loff[NCB];                    // byte offset of this lane's 4 features inside the tile's [256, 256] bf16
+                                      // rows: local_row * 512 + (lane>>4) * 8; -1 past the end of the points
+    int goff;                         // (lane>>4) * 8 bytes
+    unsigned mb[NCB][2];              // ReLU mask bits being collected [column block][pair group]
+    long long mask_tile;              // byte offset of this tile's dword 0 of layer 0 (nerf_layout::mask_offset_bytes), uniform
 };
 
 template <bool RELU>
@@ -171,10 +175,29 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
         if constexpr (SAVE) {
             // the fragment is complete: write this lane's 2 x 4 features of layer L's output
             // (row-major [P, width] bf16; features 32Q+4g.. and 32Q+16+4g..) for the backward pass
-            if (j2 == 3 && st.prow[cb] >= 0) {
-                char* rp = st.acts + act_offset_bytes(L, st.P) + st.prow[cb] * (act_width(L) * 2) + 64 * Q + st.goff;
+            if (j2 == 3 && st.loff[cb] >= 0) {
+                // wave-uniform 64-bit base (layer, tile) + 32-bit lane offset; rows of L9 are half as long
+                char* tb = st.acts + (act_offset_bytes(L, st.P) + st.tile_base * (act_width(L) * 2) + 64 * Q);
+                char* rp = tb + (unsigned)(act_width(L) == 256 ? st.loff[cb] : (st.loff[cb] + st.goff) >> 1);
                 *reinterpret_cast<f32x2*>(rp) = __builtin_bit_cast(f32x2, __builtin_shufflevector(w, w, 0, 1));
                 *reinterpret_cast<f32x2*>(rp + 32) = __builtin_bit_cast(f32x2, __builtin_shufflevector(w, w, 2, 3));
+            }
+            if constexpr (D.relu != 0) {
+                // ReLU mask for the backward pass: one bit per feature (post-ReLU bf16 != 0), collected
+                // per group of 4 pairs and written as one coalesced dword per thread
+                static_assert(NCB == 2, "mask layout: two column blocks per wave");
+                // t = {low != 0, high != 0} as 0/1 halves: one packed unsigned min with {1, 1} (hipcc
+                // lowers the generic form to two compares, two selects and a permute)
+                const unsigned wj = w[j2];
+                unsigned t;
+                asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(wj), "s"(0x00010001u));
+                const int pos = (Q & 3) * 4 + j2;
+                st.mb[cb][Q >> 2] = pos == 0 ? t : ((t << pos) | st.mb[cb][Q >> 2]);
+                if (pos == 15) {
+                    // wave-uniform 64-bit base + this thread's 32-bit offset (scalar base, one offset VGPR)
+                    char* mp = st.acts + (st.mask_tile + ((long long)L * mask_tiles(st.P) * 4 + (cb * 2 + (Q >> 2))) * 2048);
+                    *reinterpret_cast<unsigned*>(mp + (unsigned)(threadIdx.x * 4)) = st.mb[cb][Q >> 2];
+                }
             }
         }
     }
@@ -309,7 +332,7 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
     for (int cb = 0; cb < NCB; ++cb) {
         long long p = tile_base + c.wave * (16 * NCB) + cb * 16 + col;
         const bool valid = p < a.P;
-        st.prow[cb] = valid ? p : -1;
+        st.loff[cb] = valid ? (c.wave * (16 * NCB) + cb * 16 + col) * 512 + g * 8 : -1;
         if (!valid) p = a.P - 1;
         PointIn pt;
         if constexpr (RAYS) {
@@ -390,6 +413,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
         State st;
         st.acts = reinterpret_cast<char*>(a.acts);
         st.P = a.P;
+        st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
+        st.tile_base = tile_base;
         st.goff = (c.lane >> 4) * 8;
         stage_inputs<RAYS>(c, a, tile_base, st);
 

@@ -8,14 +8,15 @@
 // (mlp_bf16_16.hip; read its header first): the accumulators of one backward
 // layer, masked and converted to bf16, are the B operand of the next one, so the
 // gradient w.r.t. activations never leaves the CU.  It reads d_raw[P,4] (from
-// the compositor's backward) and the ReLU masks (the forward's saved bf16
-// activations, non-zero <=> active) and writes dY_l [P, width] bf16 row-major.
+// the compositor's backward) and the ReLU masks (one bit per feature, written by
+// the training forward in this kernel's own register layout: nerf_layout.h) and
+// writes dY_l [P, width] bf16 row-major.
 // The weight gradients dW_l = dY_l^T X_l are plain GEMMs over the point
-// dimension and run in the vendor library (training.py).
+// dimension and run in dw_gemm.hip.
 //
 // 10 backward layers (nerf_layout::bwd_desc), 38 weight chunks per tile streamed
 // L2 -> LDS by LDS-DMA exactly as in the forward.  HBM-bound by construction:
-// ~5 KB of masks read and ~5 KB of dY written per point.
+// 0.3 KB of mask bits read and ~5 KB of dY written per point.
 #include "nerf_device.h"
 #include <utility>
 
@@ -80,11 +81,13 @@ struct Ctx {
 struct State {
     ex8 X[2][8], Y[2][8];           // dY fragments, ping-pong
     f32x4 pend[2][2];               // pending pair accumulators [cb][tile]
-    u32x2 pmask[2][2];              // its ReLU-mask halves [cb][half]
+    u32x4 mk[2];                    // ReLU mask dwords of backward layer B in mk[B & 1] (nerf_layout.h)
+    long long mask_tile;            // byte offset of this tile's dword 0 of activation 0 (uniform)
     ex8 bx_rgb[2], bx_sig[2];       // custom k-steps built from d_raw
     const char* acts;
     char* dys;
-    long long P, prow[2];
+    long long P, tile_base;
+    int loff[2];                    // local_row * 512 + (lane>>4) * 8 inside the tile's rows, -1 past the end
     int goff;
 };
 
@@ -108,37 +111,36 @@ struct Stage {
     }
 };
 
-// ReLU-mask halves of pair Q of forward layer A for this lane's point of block cb
+// the four mask dwords of forward activation A for this thread's 2 x 256 (point, feature) cells
 template <int A>
-__device__ __forceinline__ void load_mask(const State& st, int cb, int Q, u32x2 (&m)[2]) {
-    m[0] = u32x2{0u, 0u};
-    m[1] = u32x2{0u, 0u};
-    if (st.prow[cb] >= 0) {
-        const char* rp = st.acts + act_offset_bytes(A, st.P) + st.prow[cb] * (act_width(A) * 2) + 64 * Q + st.goff;
-        m[0] = *reinterpret_cast<const u32x2*>(rp);
-        m[1] = *reinterpret_cast<const u32x2*>(rp + 32);
-    }
+__device__ __forceinline__ void load_mask(const State& st, u32x4& m) {
+    const char* mp = st.acts + (st.mask_tile + (long long)A * mask_tiles(st.P) * 8192);      // wave-uniform
+#pragma unroll
+    for (int d = 0; d < 4; ++d) m[d] = *reinterpret_cast<const unsigned*>(mp + d * 2048 + (unsigned)(threadIdx.x * 4));
 }
 
 // piece i of the epilogue of pair Q of backward layer B: mask, convert, and (on the
 // fragment's last word) store dY of forward layer 9-B
 template <int B, int Q>
-__device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], const u32x2 (&mask)[2][2],
-                                               ex8 (&dst)[2][8], State& st) {
+__device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], ex8 (&dst)[2][8], State& st) {
     constexpr BwdDesc D = bwd_desc(B);
     constexpr int LOUT = 9 - B;
     const int cb = i >> 2, j2 = i & 3;
     float v0 = acc[cb][j2 >> 1][2 * (j2 & 1)], v1 = acc[cb][j2 >> 1][2 * (j2 & 1) + 1];
     if constexpr (D.mask_act >= 0) {
-        const unsigned mw = mask[cb][j2 >> 1][j2 & 1];
-        v0 = (mw & 0xffffu) ? v0 : 0.f;
-        v1 = (mw >> 16) ? v1 : 0.f;
+        // bit -> all-ones / zero by a sign-extending 1-bit field extract, then AND
+        const unsigned mw = st.mk[B & 1][cb * 2 + (Q >> 2)];
+        const int pos = (Q & 3) * 4 + j2;
+        v0 = __builtin_bit_cast(float, __builtin_bit_cast(int, v0) & ((int)(mw << (31 - pos)) >> 31));
+        v1 = __builtin_bit_cast(float, __builtin_bit_cast(int, v1) & ((int)(mw << (15 - pos)) >> 31));
     }
     u32x4 w = __builtin_bit_cast(u32x4, dst[cb][Q]);
     w[j2] = pack2(v0, v1);
     dst[cb][Q] = __builtin_bit_cast(ex8, w);
-    if (j2 == 3 && st.prow[cb] >= 0) {
-        char* rp = st.dys + act_offset_bytes(LOUT, st.P) + st.prow[cb] * (act_width(LOUT) * 2) + 64 * Q + st.goff;
+    if (j2 == 3 && st.loff[cb] >= 0) {
+        // wave-uniform 64-bit base (layer, tile) + 32-bit lane offset; rows of dY9 are half as long
+        char* tb = st.dys + (act_offset_bytes(LOUT, st.P) + st.tile_base * (act_width(LOUT) * 2) + 64 * Q);
+        char* rp = tb + (unsigned)(act_width(LOUT) == 256 ? st.loff[cb] : (st.loff[cb] + st.goff) >> 1);
         *reinterpret_cast<u32x2*>(rp) = u32x2{w[0], w[1]};
         *reinterpret_cast<u32x2*>(rp + 32) = u32x2{w[2], w[3]};
     }
@@ -173,15 +175,12 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
     ex8 a[AHEAD];
 #pragma unroll
     for (int f = 0; f < AHEAD && f < F; ++f) a[f] = lds_load<ex8>(wb, f * 1024);
-    // ReLU masks of the two pairs finished by this chunk (the second is handed on as pending)
-    u32x2 m0[2][2] = {}, m1[2][2] = {};
-    if constexpr (D.mask_act >= 0) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            load_mask<D.mask_act < 0 ? 0 : D.mask_act>(st, cb, 2 * C, m0[cb]);
-            load_mask<D.mask_act < 0 ? 0 : D.mask_act>(st, cb, 2 * C + 1, m1[cb]);
-        }
+    // The next backward layer's ReLU mask is fetched a layer ahead, in this layer's SECOND chunk:
+    // mk[(B+1) & 1] also held layer B-1's mask, whose last (pending) pair is finished in chunk 0.
+    if constexpr (C == 1 && B + 1 < NUM_BWD) {
+        if constexpr (bwd_desc(B + 1).mask_act >= 0) load_mask<bwd_desc(B + 1).mask_act>(st, st.mk[(B + 1) & 1]);
     }
+    static_assert(layer_chunks(B) >= 2, "the mask prefetch lives in chunk 1");
     f32x4 acc[2][NT];
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
@@ -209,8 +208,8 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
 #pragma unroll
                         for (int k = 0; k < PEND_PER; ++k) {
                             const int i = (m - PEND_M0) * PEND_PER + k;
-                            if constexpr (PB == B) epilogue_piece<PB, PQ>(i, st.pend, st.pmask, out, st);
-                            else epilogue_piece<PB, PQ>(i, st.pend, st.pmask, in, st);
+                            if constexpr (PB == B) epilogue_piece<PB, PQ>(i, st.pend, out, st);
+                            else epilogue_piece<PB, PQ>(i, st.pend, in, st);
                         }
                     }
                 }
@@ -218,7 +217,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
                     const f32x4 pr[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
 #pragma unroll
                     for (int k = 0; k < PAIR_PER; ++k)
-                        epilogue_piece<B, 2 * C>((m - PAIR_M0) * PAIR_PER + k, pr, m0, out, st);
+                        epilogue_piece<B, 2 * C>((m - PAIR_M0) * PAIR_PER + k, pr, out, st);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -228,8 +227,6 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
     for (int cb = 0; cb < 2; ++cb) {
         st.pend[cb][0] = acc[cb][NT - 2];
         st.pend[cb][1] = acc[cb][NT - 1];
-        st.pmask[cb][0] = m1[cb][0];
-        st.pmask[cb][1] = m1[cb][1];
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
     __syncthreads();
@@ -276,11 +273,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(Bwd
         st.dys = a.dys;
         st.P = a.P;
         st.goff = g * 8;
+        st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
+        st.tile_base = tile_base;
+        load_mask<bwd_desc(0).mask_act>(st, st.mk[0]);
         const __bf16 z = (__bf16)0.f;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const long long p = tile_base + c.wave * 32 + cb * 16 + col;
-            st.prow[cb] = p < a.P ? p : -1;
+            st.loff[cb] = p < a.P ? (c.wave * 32 + cb * 16 + col) * 512 + g * 8 : -1;
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
             if (p < a.P) d = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);
             // custom k-steps: lane group 0 carries drgb (elements 0..2) / dsigma (element 0)
@@ -300,7 +300,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(Bwd
         run_layer<9>(c, st, st.X, st.Y);     // d h1
         // the last pair of d h1 is still pending
 #pragma unroll
-        for (int i = 0; i < 8; ++i) epilogue_piece<9, bwd_mt(9) / 2 - 1>(i, st.pend, st.pmask, st.Y, st);
+        for (int i = 0; i < 8; ++i) epilogue_piece<9, bwd_mt(9) / 2 - 1>(i, st.pend, st.Y, st);
     }
 }
 

@@ -268,7 +268,20 @@ constexpr long long BWD_IMAGE_BYTES = (long long)BWD_WEIGHT_KIB * 1024;
 // L0..L7 post-ReLU (256), L8 = h9 linear (256), L9 = c post-ReLU (128)
 NL_HD constexpr int act_width(int L) { return L == 9 ? 128 : 256; }
 NL_HD constexpr long long act_offset_bytes(int L, long long P) { return (long long)L * P * 512; }
-NL_HD constexpr long long acts_total_bytes(long long P) { return 9 * P * 512 + P * 256; }
+NL_HD constexpr long long acts_bf16_bytes(long long P) { return 9 * P * 512 + P * 256; }
+// ReLU masks of the saved activations, one bit per feature, in the MLP kernels' own register
+// layout so the forward writes and the backward reads them as coalesced dwords: per (layer L,
+// tile of 256 points) 4 dwords x 512 threads.  Thread (wave, lane) holds, for its column block
+// cb and feature-pair group Q>>2, dword cb*2 + (Q>>2): bit (Q&3)*4 + j <-> the low bf16 of
+// word j of fragment Q, bit 16 + (Q&3)*4 + j the high one (word j = features 32Q + 16(j>>1) +
+// 4g + 2(j&1) + {0,1} of the lane's point).  They follow the bf16 activations in the buffer.
+constexpr int MASK_TILE_PTS = 256;
+NL_HD constexpr long long mask_tiles(long long P) { return (P + MASK_TILE_PTS - 1) / MASK_TILE_PTS; }
+NL_HD constexpr long long mask_region_offset(long long P) { return acts_bf16_bytes(P); }
+NL_HD constexpr long long mask_offset_bytes(int L, long long tile, int dword, long long P) {
+    return mask_region_offset(P) + (((long long)L * mask_tiles(P) + tile) * 4 + dword) * 2048;   // + tid * 4
+}
+NL_HD constexpr long long acts_total_bytes(long long P) { return acts_bf16_bytes(P) + 10 * mask_tiles(P) * 8192; }
 // saved backward pre-activation gradients dY (bf16, row-major), same indexing:
 // dY[L] has the width of layer L's output
 
