@@ -121,8 +121,9 @@ struct State {
     long long P;
     long long tile_base;              // first point of the tile (uniform)
     int loff[NCB];                    // byte offset of this lane's 4 features inside the tile's [256, 256] bf16
-                                      // rows: local_row * 512 + (lane>>4) * 8; -1 past the end of the points
-    int goff;                         // (lane>>4) * 8 bytes
+                                      // rows: local_row * 512 + (lane>>4) * 8; LOFF_INVALID past the end
+    int tile_rows;                    // points of this tile that exist (uniform)
+    int goff;                         // swapped_goff(lane>>4): this lane's 16 bytes inside a 64-byte fragment row
     unsigned mb[NCB][2];              // ReLU mask bits being collected [column block][pair group]
     long long mask_tile;              // byte offset of this tile's dword 0 of layer 0 (nerf_layout::mask_offset_bytes), uniform
 };
@@ -175,12 +176,23 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
         if constexpr (SAVE) {
             // the fragment is complete: write this lane's 2 x 4 features of layer L's output
             // (row-major [P, width] bf16; features 32Q+4g.. and 32Q+16+4g..) for the backward pass
-            if (j2 == 3 && st.loff[cb] >= 0) {
-                // wave-uniform 64-bit base (layer, tile) + 32-bit lane offset; rows of L9 are half as long
-                char* tb = st.acts + (act_offset_bytes(L, st.P) + st.tile_base * (act_width(L) * 2) + 64 * Q);
-                char* rp = tb + (unsigned)(act_width(L) == 256 ? st.loff[cb] : (st.loff[cb] + st.goff) >> 1);
-                *reinterpret_cast<f32x2*>(rp) = __builtin_bit_cast(f32x2, __builtin_shufflevector(w, w, 0, 1));
-                *reinterpret_cast<f32x2*>(rp + 32) = __builtin_bit_cast(f32x2, __builtin_shufflevector(w, w, 2, 3));
+            if (j2 == 3) {
+                // range-checked buffer stores over (layer, tile): unconditional, so the number of
+                // vector-memory instructions per chunk is a constant (chunk_barrier) and lanes past
+                // the last point fall outside num_records
+                constexpr int RB = act_width(L) * 2;
+                char* tb = st.acts + (act_offset_bytes(L, st.P) + st.tile_base * RB);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, st.tile_rows * RB, 0x00020000);
+                const int vo = RB == 512 ? st.loff[cb] : (st.loff[cb] + st.goff) >> 1;   // rows of L9 are half as long
+                // The lane holds two 8-byte pieces 32 bytes apart (features 32Q+4g.. and 32Q+16+4g..).
+                // v_permlane16_swap trades one piece with the neighbouring 16-lane row (g ^ 1): even g
+                // ends up with [its first piece | g+1's first piece], odd g with [g-1's second piece |
+                // its second piece] -- 16 contiguous bytes each, one store instead of two (the
+                // epilogue is store-issue-bound: cdna_hip_programming.md T21).  loff carries the
+                // swapped position: g -> byte 0, 32, 16, 48 of the 64-byte group for g = 0, 1, 2, 3.
+                const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs, vo, 64 * Q, 0);
             }
             if constexpr (D.relu != 0) {
                 // ReLU mask for the backward pass: one bit per feature (post-ReLU bf16 != 0), collected
@@ -201,6 +213,13 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
             }
         }
     }
+}
+
+// vector-memory instructions epilogue_piece<L, Q, SAVE> issues over its 4*NCB pieces
+template <bool SAVE>
+__host__ __device__ constexpr int pair_vmem_ops(int L, int Q) {
+    if (!SAVE || L < 0 || L == 10 || (L == 8 && Q == 8)) return 0;
+    return NCB + ((layer_desc(L).relu != 0 && (Q & 3) == 3) ? NCB : 0);    // activations (+ a mask dword) per block
 }
 
 // ---- one chunk: NT 16-row tiles of layer L starting at tile 4C -------------------
@@ -232,6 +251,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
 #if !defined(NERF_EXP) || NERF_EXP != 4
     Stage<CC>::issue(c);            // (ablation NERF_EXP=4: no weight DMA; results are garbage)
 #endif
+    __builtin_amdgcn_sched_barrier(0);   // every other vector-memory instruction of the chunk stays behind the DMA
 
     ex8 a[AHEAD];
 #pragma unroll
@@ -296,8 +316,8 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
 #if defined(NERF_EXP) && NERF_EXP == 3
     // ablation: no chunk barrier (races: results are garbage; timing only)
 #else
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
-    __syncthreads();
+    // this wave's LDS-DMA pieces (issued first in this chunk) have landed; the stores behind them may fly on
+    chunk_barrier<pair_vmem_ops<SAVE>(PL, PQ) + (NT == 4 ? pair_vmem_ops<SAVE>(L, 2 * C) : 0)>();
 #endif
 }
 
@@ -332,7 +352,7 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
     for (int cb = 0; cb < NCB; ++cb) {
         long long p = tile_base + c.wave * (16 * NCB) + cb * 16 + col;
         const bool valid = p < a.P;
-        st.loff[cb] = valid ? (c.wave * (16 * NCB) + cb * 16 + col) * 512 + g * 8 : -1;
+        st.loff[cb] = valid ? (c.wave * (16 * NCB) + cb * 16 + col) * 512 + swapped_goff(g) : LOFF_INVALID;
         if (!valid) p = a.P - 1;
         PointIn pt;
         if constexpr (RAYS) {
@@ -415,7 +435,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
         st.P = a.P;
         st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
         st.tile_base = tile_base;
-        st.goff = (c.lane >> 4) * 8;
+        st.tile_rows = (int)(a.P - tile_base < TILE_PTS ? a.P - tile_base : TILE_PTS);
+        st.goff = swapped_goff(c.lane >> 4);
         stage_inputs<RAYS>(c, a, tile_base, st);
 
         run_layer<0, SAVE>(c, st, st.X, st.X);

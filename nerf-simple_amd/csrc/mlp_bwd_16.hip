@@ -87,7 +87,8 @@ struct State {
     const char* acts;
     char* dys;
     long long P, tile_base;
-    int loff[2];                    // local_row * 512 + (lane>>4) * 8 inside the tile's rows, -1 past the end
+    int loff[2];                    // local_row * 512 + (lane>>4) * 8 inside the tile's rows, LOFF_INVALID past the end
+    int tile_rows;                  // points of this tile that exist (uniform)
     int goff;
 };
 
@@ -137,12 +138,16 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
     u32x4 w = __builtin_bit_cast(u32x4, dst[cb][Q]);
     w[j2] = pack2(v0, v1);
     dst[cb][Q] = __builtin_bit_cast(ex8, w);
-    if (j2 == 3 && st.loff[cb] >= 0) {
-        // wave-uniform 64-bit base (layer, tile) + 32-bit lane offset; rows of dY9 are half as long
-        char* tb = st.dys + (act_offset_bytes(LOUT, st.P) + st.tile_base * (act_width(LOUT) * 2) + 64 * Q);
-        char* rp = tb + (unsigned)(act_width(LOUT) == 256 ? st.loff[cb] : (st.loff[cb] + st.goff) >> 1);
-        *reinterpret_cast<u32x2*>(rp) = u32x2{w[0], w[1]};
-        *reinterpret_cast<u32x2*>(rp + 32) = u32x2{w[2], w[3]};
+    if (j2 == 3) {
+        // range-checked buffer stores over (layer, tile), unconditional: see chunk_barrier
+        constexpr int RB = act_width(LOUT) * 2;
+        char* tb = st.dys + (act_offset_bytes(LOUT, st.P) + st.tile_base * RB);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, st.tile_rows * RB, 0x00020000);
+        const int vo = RB == 512 ? st.loff[cb] : (st.loff[cb] + st.goff) >> 1;       // rows of dY9 are half as long
+        // one 16-byte store after trading 8-byte pieces with lane group g ^ 1 (forward epilogue_piece)
+        const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
+        const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs, vo, 64 * Q, 0);
     }
 }
 
@@ -171,6 +176,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
     static_assert(bwd_mt(B) % TPC == 0, "row tiles per backward layer");
 
     Stage<CC>::issue(c);
+    __builtin_amdgcn_sched_barrier(0);   // every other vector-memory instruction of the chunk stays behind the DMA
 
     ex8 a[AHEAD];
 #pragma unroll
@@ -228,8 +234,10 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
         st.pend[cb][0] = acc[cb][NT - 2];
         st.pend[cb][1] = acc[cb][NT - 1];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
-    __syncthreads();
+    // this wave's LDS-DMA pieces (issued first in this chunk) have landed; what follows them may fly on:
+    // 2 dY stores per finished pair (pending + this chunk's own) and the 4 mask loads of chunk 1
+    constexpr bool PREFETCH = C == 1 && B + 1 < NUM_BWD && bwd_desc(B + 1 < NUM_BWD ? B + 1 : B).mask_act >= 0;
+    chunk_barrier<(PB >= 0 ? 2 : 0) + 2 + (PREFETCH ? 4 : 0)>();
 }
 
 __host__ __device__ constexpr int prev_layer(int b, int C) { return C > 0 ? b : b - 1; }
@@ -272,15 +280,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(Bwd
         st.acts = a.acts;
         st.dys = a.dys;
         st.P = a.P;
-        st.goff = g * 8;
+        st.goff = swapped_goff(g);
         st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
         st.tile_base = tile_base;
+        st.tile_rows = (int)(a.P - tile_base < TILE_PTS ? a.P - tile_base : TILE_PTS);
         load_mask<bwd_desc(0).mask_act>(st, st.mk[0]);
         const __bf16 z = (__bf16)0.f;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const long long p = tile_base + c.wave * 32 + cb * 16 + col;
-            st.loff[cb] = p < a.P ? (c.wave * 32 + cb * 16 + col) * 512 + g * 8 : -1;
+            st.loff[cb] = p < a.P ? (c.wave * 32 + cb * 16 + col) * 512 + swapped_goff(g) : LOFF_INVALID;
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
             if (p < a.P) d = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);
             // custom k-steps: lane group 0 carries drgb (elements 0..2) / dsigma (element 0)

@@ -35,6 +35,25 @@ struct MlpArgs {
     unsigned flags;
 };
 
+// ---- chunk barrier of the MLP kernels --------------------------------------------
+// Loads, LDS-DMA and stores share vmcnt on gfx9-family parts and retire in issue order, so
+// "this wave's DMA pieces have landed" is vmcnt(N) with N = the vector-memory instructions the
+// wave issued AFTER its DMA pieces in this chunk (activation / dY / mask stores, mask loads).
+// Waiting for vmcnt(0) instead -- which __syncthreads() also does through its release fence --
+// stalls every chunk on the round trip of the stores just issued.  N is a compile-time count;
+// tests/test_library_cpu.py::test_counted_vmcnt_waits checks it against the generated ISA.
+constexpr int LOFF_INVALID = 0x40000000;      // lane offset of a point past the end: out of any buffer range
+// byte offset of lane group g's 16 bytes inside a 64-byte fragment row once the 8-byte pieces
+// have been traded with v_permlane16_swap (mlp_bf16_16.hip epilogue_piece): g = 0,1,2,3 -> 0,32,16,48
+__host__ __device__ constexpr int swapped_goff(int g) { return (g & 1) * 32 + (g >> 1) * 16; }
+
+template <int N>
+__device__ __forceinline__ void chunk_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");            // nothing below is hoisted above the barrier
+}
+
 // ---- counter RNG: Philox-4x32-10 (Salmon et al. 2011), keyed by seed,
 // counter = global sample id.  One 32-bit word -> u in [0,1) with 24 bits, the
 // same granularity as torch.rand for float32.

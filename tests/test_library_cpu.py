@@ -163,3 +163,26 @@ def test_checkpoint_roundtrip(tmp_path, synthetic):
     torch.save(bad, str(tmp_path / "bad.pth"))
     with pytest.raises(KeyError):
         checkpoint.load_checkpoint(Nerf(), str(tmp_path / "bad.pth"))
+
+
+def test_counted_vmcnt_waits():
+    """Each chunk barrier of the MLP kernels waits for vmcnt(N), N = the vector-memory
+    instructions issued after the chunk's LDS-DMA pieces (csrc/nerf_device.h chunk_barrier).
+    The count is a compile-time formula; this checks it against the generated gfx950 ISA
+    (too small an N would be a race on the weight buffer)."""
+    import shutil
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import check_vmcnt
+    finally:
+        sys.path.pop(0)
+    for src, kernels, waits in (("mlp_bf16_16.hip", 3, 41), ("mlp_bwd_16.hip", 1, 39)):
+        res = check_vmcnt.check_source(os.path.join(root, "nerf-simple_amd", "csrc", src))
+        assert len(res) == kernels, (src, list(res))
+        for name, (checked, bad) in res.items():
+            assert checked == waits, (src, name, checked)
+            assert not bad, (src, name, bad[:5])
