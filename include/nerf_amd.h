@@ -172,20 +172,22 @@ int nerf_amd_sample_encode(const float* rays, const float* u, const float* tbins
                            float* posx, float* posd, float* ts, int64_t B, int N, void* stream);
 
 /* ---- fused training path of the dense layers (reference train.py:51-54) --------
- * Forward as nerf_amd_mlp_forward_rays (bf16) that ALSO saves every layer's output
- * (bf16, row-major, layer L at byte offset L*P*512: L0..L7 post-ReLU [P,256], L8 = the
- * linear 256->256 [P,256], L9 = colour hidden [P,128]; P = B*N) for the weight gradients,
- * followed at byte 9*P*512 + P*256 by the ReLU masks for the dX chain: one bit per
- * feature, 10 * ceil(P/256) * 8 KiB, in the kernels' register order (layout and bit
- * assignment: csrc/nerf_layout.h, mask_offset_bytes; decoded in tests/test_gpu_training.py). */
+ * Forward as nerf_amd_mlp_forward_rays (bf16) that ALSO saves every layer's output for the
+ * weight gradients (bf16; L0..L7 post-ReLU 256 features, L8 = the linear 256->256, L9 = colour
+ * hidden 128; P = B*N points) in the point-blocked layout the kernels write and read with
+ * contiguous 256-byte runs: layer L at L * ceil(P/256) * 128 KiB, inside it tile t (256 points)
+ * at t * 128 KiB as [feature/8 (32)][point in tile (256)][8 bf16].  Then, at
+ * 10 * ceil(P/256) * 128 KiB, the ReLU masks for the dX chain: one bit per feature,
+ * 10 * ceil(P/256) * 8 KiB, in the kernels' register order.  (Both layouts: csrc/nerf_layout.h;
+ * decoded in tests/test_gpu_training.py.) */
 int64_t nerf_amd_train_activation_bytes(int64_t P);
 int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* tbins,
                                const void* packed_bf16, uint32_t flags, uint64_t seed, int64_t ray_id0,
                                float* raw, float* ts, void* acts, int64_t B, int N, void* stream);
 /* Backward dX chain: d_raw[P,4] (from nerf_amd_volume_render_backward) + the ReLU
  * mask bits inside `acts` (the bf16 activations themselves are not read here) ->
- * dys: every layer's pre-activation gradient, bf16 row-major, same layout as the
- * bf16 part of `acts`.  The gradient w.r.t. activations stays on-chip between
+ * dys: every layer's pre-activation gradient, bf16, point-blocked like the bf16 part
+ * of `acts`.  The gradient w.r.t. activations stays on-chip between
  * layers.  `bwd_image` from nerf_amd_pack_weights(..., NERF_AMD_BF16_BWD).  Weight
  * gradients are then dW_L = dys[L]^T @ input_L: nerf_amd_param_gradients. */
 int nerf_amd_mlp_backward(const float* d_raw, const void* bwd_image, const void* acts,

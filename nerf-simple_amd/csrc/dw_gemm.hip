@@ -35,8 +35,8 @@ namespace {
 
 constexpr int MAXD = 16;
 struct GemmDesc {
-    const __bf16* A;   // [P, lda], columns 0..M-1 become output ROWS
-    const __bf16* B;   // [P, ldb], columns 0..N-1 become output COLUMNS
+    const __bf16* A;   // [P, lda] row-major, or (lda == 0) one point-blocked activation layer; columns 0..M-1 -> output ROWS
+    const __bf16* B;   // [P, ldb] row-major, or (ldb == 0) point-blocked;                          columns 0..N-1 -> output COLUMNS
     float* C;          // destination of output element (r0, 0)
     int lda, ldb, ldc;
     int M, N;          // operand widths actually read (multiples of 32)
@@ -52,8 +52,10 @@ struct GemmTable {
 
 constexpr int SLAB = 32;                       // points per LDS slab (2 k-steps of 16)
 static_assert(SLAB == 32, "the slab loop is written for two k-steps");
+static_assert(ACT_TILE_PTS % SLAB == 0 && ACT_TILE_PTS * 16 == 4096, "a slab never straddles activation blocks");
 constexpr int ROWB = 512;                      // LDS row = 256 bf16 features, unpadded (LDS-DMA is lane-linear)
 constexpr int OPB = SLAB * ROWB;               // one operand slab = 16 KiB
+constexpr int KSTEP = 16 * ROWB;               // second k-step (points 16..31) of either LDS image form
 constexpr int SLOTB = 2 * OPB;                 // A + B
 constexpr int RING = 4;                        // slabs resident in LDS: one computing, up to three landing
 constexpr int LDS_BYTES = RING * SLOTB;        // 128 KiB
@@ -62,21 +64,26 @@ constexpr int DMA_PER_SLAB = 2 * SLAB / 2 / 8; // 1 KiB wave-instructions per wa
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) void lds_void;
 
-// LDS image: row r (a point) holds its 32 16-byte chunks at positions chunk ^ ((r & 3) << 2).
-// The LDS-DMA destination is lane-linear, so the swizzle is applied to each lane's SOURCE chunk
-// and again to the read address (cdna_hip_programming.md section 5.4 rule 21).  With it the 8
-// (row, 32-byte) pieces a half-wave touches in one ds_read_b64_tr_b16 fall in 8 distinct
-// 32-byte slots of the 256-byte bank row: conflict-free without padding.
+// LDS image of one operand slab (32 points x 32 chunks of 16 B = 16 KiB), two forms, both filled
+// by lane-linear LDS-DMA with the swizzle applied to each lane's SOURCE granule and again to the
+// read address (cdna_hip_programming.md section 5.4 rule 21), both conflict-free for
+// ds_read_b64_tr_b16 (the 32 lanes of a half-wave touch 32 distinct 8-byte words of a 256-byte
+// bank row) and both with the second k-step 8 KiB after the first:
+//   row-major operand (posx / posd / d_raw rows):  granule (point r, chunk c) at
+//       r * 512 + (c ^ ((r & 3) << 2)) * 16                 -- a DMA instruction = 2 rows;
+//   point-blocked operand (activations, dY):        granule (point r = 16 ks + r', chunk c) at
+//       ks * 8192 + c * 256 + (r' ^ ((c & 3) << 2)) * 16    -- a DMA instruction = 4 chunks x 16
+//       points, i.e. four 256-byte contiguous runs of the block in HBM.
 // The transposing reads are issued through inline asm: hipcc treats the ds_read_tr builtin as a
 // possible alias of every LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of it, which
 // would drain the three-slab prefetch each slab.  The asm reads are invisible to the compiler's
 // counters, so their lgkmcnt wait is explicit too (frags_landed ties the registers to the wait).
 struct Frag { bf16x4 lo, hi; };                    // k = 8h + 0..3 and 8h + 4..7 of this lane's column
-__device__ __forceinline__ void read_frag_tr(Frag& f, unsigned addr) {
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:2048"
-                 : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr));
+template <int KOFF>
+__device__ __forceinline__ void read_frag_tr(Frag& f, unsigned addr_lo, unsigned addr_hi) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%4\n\tds_read_b64_tr_b16 %1, %3 offset:%4"
+                 : "=&v"(f.lo), "=&v"(f.hi) : "v"(addr_lo), "v"(addr_hi), "n"(KOFF));
 }
-static_assert(4 * ROWB == 2048, "second transposing read is 4 rows further");
 __device__ __forceinline__ void frags_landed(Frag (&a)[4], Frag (&b)[2]) {
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(a[0].lo), "+v"(a[0].hi), "+v"(a[1].lo), "+v"(a[1].hi), "+v"(a[2].lo), "+v"(a[2].hi),
@@ -101,51 +108,83 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
     const int wm = wave >> 2, wn = wave & 3;          // 2 x 4 waves over the 256 x 256 tile
     const int m0 = 128 * wm, n0 = 64 * wn;            // this wave: 4 x 2 tiles of 32 x 32
 
-    // ---- LDS-DMA geometry: wave w issues pieces 4w .. 4w+3 of a slab; piece i = operand i>>4,
-    // row pair i&15; lane l lands at row 2(i&15) + (l>>5), chunk position l&31
-    // The descriptors are rebased to this workgroup's K slice and end at min(P, slice end): rows
-    // past the operand return zeros through the VGPR-offset range check (the SGPR offset is not
-    // range-checked on gfx9-family raw buffers, so the slab offset travels in the VGPR).
+    // ---- LDS-DMA geometry: wave w issues pieces 4w .. 4w+3 of a slab (pieces 0..15: A, 16..31: B);
+    // a piece is 1 KiB of the operand's LDS image, lane l at byte 16 l of it
+    const bool pieceA = wave < 4;
+    const int pld = pieceA ? d.lda : d.ldb;           // 0: point-blocked
+    const bool pblk = pld == 0;
+    const __bf16* pbase = pieceA ? d.A : d.B;
+    const int pwidth = pieceA ? d.M : d.N;
     const long long row_begin = s_begin * SLAB;
     const long long row_end = s_end * SLAB < tab.P ? s_end * SLAB : tab.P;
     const long long slice_rows = row_end > row_begin ? row_end - row_begin : 0;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16*>(d.A + row_begin * d.lda), 0, (int)(slice_rows * d.lda * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16*>(d.B + row_begin * d.ldb), 0, (int)(slice_rows * d.ldb * 2), 0x00020000);
+    // Both forms: descriptor rebased to this workgroup's K slice (below 1 GiB: launcher), every
+    // offset in the per-lane VGPR offset, which is what the range check sees for certain.
+    // Row-major: the range ends at min(P, slice end), so rows past the operand return zeros.
+    // Point-blocked: the range covers the slice's blocks; lanes of points >= P are pointed outside
+    // by hand (their granules lie between valid ones).
+    const long long slice_blocks = (row_end + ACT_TILE_PTS - 1) / ACT_TILE_PTS - row_begin / ACT_TILE_PTS;
+    const __amdgpu_buffer_rsrc_t rs = pblk
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(pbase))
+                                                + (row_begin / ACT_TILE_PTS) * ACT_BLOCK_BYTES,
+                                            0, (int)(slice_rows > 0 ? slice_blocks * ACT_BLOCK_BYTES : 0), 0x00020000)
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(pbase + row_begin * pld), 0,
+                                            (int)(slice_rows * pld * 2), 0x00020000);
     constexpr unsigned OUTSIDE = 0xffffffffu;         // >= num_records: the lane loads zeros
     unsigned voff[DMA_PER_SLAB];                      // per-lane source offset inside a slab
     unsigned ldst[DMA_PER_SLAB];                      // wave-uniform destination inside a ring slot
-    const bool pieceA = wave < 4;                     // pieces 0..15 are A, 16..31 are B
-    const int pld = pieceA ? d.lda : d.ldb;
+    int vrow[DMA_PER_SLAB];                           // point (row of the slab) the lane fetches
 #pragma unroll
     for (int k = 0; k < DMA_PER_SLAB; ++k) {
-        const int piece = wave * DMA_PER_SLAB + k, rowpair = piece & 15;
-        const int row = 2 * rowpair + (lane >> 5);
-        const int cg = (lane & 31) ^ ((row & 3) << 2);                    // the global chunk this LDS position holds
-        const int width = pieceA ? d.M : d.N;
-        voff[k] = cg * 8 < width ? (unsigned)(row * pld * 2 + cg * 16) : OUTSIDE;
-        ldst[k] = (piece >> 4) * OPB + rowpair * 1024;
+        const int piece = wave * DMA_PER_SLAB + k, pi = piece & 15;
+        ldst[k] = (piece >> 4) * OPB + pi * 1024;
+        if (pblk) {
+            const int c = 4 * (pi & 7) + (lane >> 4);                              // chunk
+            vrow[k] = 16 * (pi >> 3) + ((lane & 15) ^ ((lane >> 4) << 2));         // (c & 3) == lane >> 4
+            voff[k] = c * 8 < pwidth ? (unsigned)(c * (ACT_TILE_PTS * 16) + vrow[k] * 16) : OUTSIDE;
+        } else {
+            vrow[k] = 2 * pi + (lane >> 5);
+            const int cg = (lane & 31) ^ ((vrow[k] & 3) << 2);                     // the chunk this LDS position holds
+            voff[k] = cg * 8 < pwidth ? (unsigned)(vrow[k] * pld * 2 + cg * 16) : OUTSIDE;
+        }
     }
     auto issue_slab = [&](int it, int slot) {         // it = slab index inside the slice
-        const unsigned slab_off = (unsigned)it * (unsigned)(SLAB * pld * 2);
+        const long long p0 = row_begin + (long long)it * SLAB;
+        unsigned vadd;
+        int rows_left = SLAB;
+        if (pblk) {
+            vadd = (unsigned)((p0 / ACT_TILE_PTS - row_begin / ACT_TILE_PTS) * ACT_BLOCK_BYTES + (p0 % ACT_TILE_PTS) * 16);
+            rows_left = tab.P - p0 < SLAB ? (int)(tab.P - p0) : SLAB;
+        } else {
+            vadd = (unsigned)it * (unsigned)(SLAB * pld * 2);
+        }
 #pragma unroll
         for (int k = 0; k < DMA_PER_SLAB; ++k) {
             lds_void* dst = reinterpret_cast<lds_void*>(reinterpret_cast<lds_char*>(0) + slot * SLOTB + ldst[k]);
-            const unsigned off = voff[k] == OUTSIDE ? OUTSIDE : voff[k] + slab_off;
-            if (pieceA) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, dst, 16, off, 0, 0, 0);
-            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, dst, 16, off, 0, 0, 0);
+            const unsigned off = (voff[k] == OUTSIDE || vrow[k] >= rows_left) ? OUTSIDE : voff[k] + vadd;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, off, 0, 0, 0);
         }
     };
 
-    // ---- fragment addresses: row (8h + q), logical chunk 4*tile + 2(group&1) + (p>>1), swizzled by q
+    // ---- fragment addresses (first / second transposing read), per operand form.  The lane reads
+    // points 8h + q (+4) of the k-step for features 32 t + 16 (group & 1) + 4 pp .. +3 of tile t,
+    // i.e. chunk 4 t + 2 (group & 1) + (pp >> 1), bytes 8 (pp & 1) .. +7 of the granule.
     const int grp = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3, h = lane >> 5;
-    const unsigned lane_off = (8 * h + q) * ROWB + (2 * (grp & 1) + (pp >> 1)) * 16 + 8 * (pp & 1);
-    unsigned aoff[4], boff[2];
+    const int cl = 2 * (grp & 1) + (pp >> 1);          // chunk inside the tile's 4
+    auto frag_addr = [&](bool blocked, int t, int second) -> unsigned {
+        const int r = 8 * h + q + 4 * second;
+        if (blocked) return (4 * t + cl) * 256 + ((r ^ (cl << 2)) * 16) + 8 * (pp & 1);
+        return r * ROWB + ((((4 * t + cl) ^ ((r & 3) << 2))) * 16) + 8 * (pp & 1);
+    };
+    unsigned aoff[4][2], boff[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) aoff[i] = lane_off + (((m0 / 32 + i) ^ q) << 6);
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) boff[j] = OPB + lane_off + (((n0 / 32 + j) ^ q) << 6);
+        for (int e = 0; e < 2; ++e) aoff[i][e] = frag_addr(d.lda == 0, m0 / 32 + i, e);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) boff[j][e] = OPB + frag_addr(d.ldb == 0, n0 / 32 + j, e);
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -156,9 +195,11 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // waves whose tile rows / columns lie outside the product skip the arithmetic
     const bool active = m0 < d.M && n0 < d.N;
-    // db = column sums of dY (the A operand): thread -> logical chunk tid&31, rows (tid>>5) + 16 i
+    // db = column sums of dY (the A operand, point-blocked): thread -> chunk tid >> 4, points (tid & 15) + 16 ks,
+    // so a quarter-wave reads 256 contiguous bytes
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int brow = tid >> 5, bchunk = tid & 31;
+    const int brow = tid & 15, bchunk = tid >> 4;
+    const unsigned baddr = bchunk * 256 + ((brow ^ ((bchunk & 3) << 2)) * 16);
 
     // prologue: up to RING-1 slabs in flight
 #pragma unroll
@@ -178,14 +219,14 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
             // two k-steps per slab: the second step's fragments are read under the first step's MFMAs
             Frag a0[4], b0[2], a1[4], b1[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) read_frag_tr(a0[i], base + aoff[i]);
+            for (int i = 0; i < 4; ++i) read_frag_tr<0>(a0[i], base + aoff[i][0], base + aoff[i][1]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) read_frag_tr(b0[j], base + boff[j]);
+            for (int j = 0; j < 2; ++j) read_frag_tr<0>(b0[j], base + boff[j][0], base + boff[j][1]);
             frags_landed(a0, b0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) read_frag_tr(a1[i], base + aoff[i] + 16 * ROWB);
+            for (int i = 0; i < 4; ++i) read_frag_tr<KSTEP>(a1[i], base + aoff[i][0], base + aoff[i][1]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) read_frag_tr(b1[j], base + boff[j] + 16 * ROWB);
+            for (int j = 0; j < 2; ++j) read_frag_tr<KSTEP>(b1[j], base + boff[j][0], base + boff[j][1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -202,10 +243,9 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
         }
         if (d.bias && bchunk * 8 < d.M) {
 #pragma unroll
-            for (int i = 0; i < SLAB / 16; ++i) {
-                const int r = brow + 16 * i;
+            for (int ks = 0; ks < SLAB / 16; ++ks) {
                 const bf16x8 v = *reinterpret_cast<const __attribute__((address_space(3))) bf16x8*>(
-                    reinterpret_cast<lds_char*>(0) + base + r * ROWB + ((bchunk ^ ((r & 3) << 2)) << 4));
+                    reinterpret_cast<lds_char*>(0) + base + ks * KSTEP + baddr);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) bsum[k] += (float)v[k];
             }
@@ -288,8 +328,10 @@ extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* a
     const __bf16* posx = reinterpret_cast<const __bf16*>(posx64_v);
     const __bf16* posd = reinterpret_cast<const __bf16*>(posd32_v);
     __bf16* dsr = reinterpret_cast<__bf16*>(scratch);
-    auto act = [&](int L) { return acts + (long long)L * P * 256; };      // bf16 elements: L*P*512 bytes
-    auto dy = [&](int L) { return dys + (long long)L * P * 256; };
+    // point-blocked activation layers (nerf_layout.h): layer L at L * act_layer_stride(P) bytes; leading dimension 0
+    auto act = [&](int L) { return acts + act_offset_bytes(L, P) / 2; };
+    auto dy = [&](int L) { return dys + act_offset_bytes(L, P) / 2; };
+    constexpr int BLK = 0;
 
     hipLaunchKernelGGL(pack_draw_kernel, dim3(512), dim3(256), 0, stream, d_raw, dsr, P, grads + OFF_C1_B,
                        grads + OFF_SIG_B);
@@ -302,22 +344,22 @@ extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* a
         GemmDesc& g = t.d[n++];
         g.A = A; g.lda = lda; g.M = M; g.B = B; g.ldb = ldb; g.N = N;
         g.C = grads + coff; g.ldc = ldc; g.r0 = r0; g.Mv = Mv; g.Nv = Nv;
-        g.bias = boff >= 0 ? grads + boff : nullptr;      // db of the layer whose dY is this product's A
+        g.bias = boff >= 0 ? grads + boff : nullptr;      // db of the layer whose dY is this product's A (point-blocked A only)
     };
     const int LW = 256 * 256 + 256;
-    add(dy(0), 256, 256, posx, 64, 64, OFF_L0_W, 63, 0, 256, 63, OFF_L0_B);               // layers_0.0
+    add(dy(0), BLK, 256, posx, 64, 64, OFF_L0_W, 63, 0, 256, 63, OFF_L0_B);               // layers_0.0
     for (int l = 1; l <= 4; ++l)                                                          // layers_0.{2,4,6,8}
-        add(dy(l), 256, 256, act(l - 1), 256, 256, OFF_L1_W + (l - 1) * LW, 256, 0, 256, 256,
+        add(dy(l), BLK, 256, act(l - 1), BLK, 256, OFF_L1_W + (l - 1) * LW, 256, 0, 256, 256,
             OFF_L1_W + (l - 1) * LW + 65536);
-    add(dy(5), 256, 256, act(4), 256, 256, OFF_SKIP_W, 319, 0, 256, 256, OFF_SKIP_B);     // skip [h ; x]: h part
-    add(dy(5), 256, 256, posx, 64, 64, OFF_SKIP_W + 256, 319, 0, 256, 63);                //               x part
-    add(dy(6), 256, 256, act(5), 256, 256, OFF_L6_W, 256, 0, 256, 256, OFF_L6_W + 65536); // layers_1.0
-    add(dy(7), 256, 256, act(6), 256, 256, OFF_L6_W + LW, 256, 0, 256, 256, OFF_L6_W + LW + 65536);  // layers_1.2
-    add(dsr, 32, 32, act(7), 256, 256, OFF_SIG_W, 256, 3, 1, 256);                        // sigma_fc.0 (row 3 of dsr)
-    add(dy(8), 256, 256, act(7), 256, 256, OFF_L2_W, 256, 0, 256, 256, OFF_L2_B);         // layers_2
-    add(dy(9), 128, 128, act(8), 256, 256, OFF_C0_W, 283, 0, 128, 256, OFF_C0_B);         // color_fc.0 [h ; d]: h part
-    add(dy(9), 128, 128, posd, 32, 32, OFF_C0_W + 256, 283, 0, 128, 27);                  //                      d part
-    add(dsr, 32, 32, act(9), 128, 128, OFF_C1_W, 128, 0, 3, 128);                         // color_fc.2 (rows 0..2)
+    add(dy(5), BLK, 256, act(4), BLK, 256, OFF_SKIP_W, 319, 0, 256, 256, OFF_SKIP_B);     // skip [h ; x]: h part
+    add(dy(5), BLK, 256, posx, 64, 64, OFF_SKIP_W + 256, 319, 0, 256, 63);                //               x part
+    add(dy(6), BLK, 256, act(5), BLK, 256, OFF_L6_W, 256, 0, 256, 256, OFF_L6_W + 65536); // layers_1.0
+    add(dy(7), BLK, 256, act(6), BLK, 256, OFF_L6_W + LW, 256, 0, 256, 256, OFF_L6_W + LW + 65536);  // layers_1.2
+    add(dsr, 32, 32, act(7), BLK, 256, OFF_SIG_W, 256, 3, 1, 256);                        // sigma_fc.0 (row 3 of dsr)
+    add(dy(8), BLK, 256, act(7), BLK, 256, OFF_L2_W, 256, 0, 256, 256, OFF_L2_B);         // layers_2
+    add(dy(9), BLK, 128, act(8), BLK, 256, OFF_C0_W, 283, 0, 128, 256, OFF_C0_B);         // color_fc.0 [h ; d]: h part
+    add(dy(9), BLK, 128, posd, 32, 32, OFF_C0_W + 256, 283, 0, 128, 27);                  //                      d part
+    add(dsr, 32, 32, act(9), BLK, 128, OFF_C1_W, 128, 0, 3, 128);                         // color_fc.2 (rows 0..2)
     t.n = n;
     // workgroups per product, one per CU in total.  A slab costs a workgroup the bytes it streams,
     // (M + N) * 2 per point, plus a fixed part (barrier, DMA issue, fragment reads) that measures

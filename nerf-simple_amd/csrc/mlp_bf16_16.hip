@@ -89,6 +89,8 @@ constexpr int LDS_TOTAL = LDS_POSX + WAVES * NCB * 2048;
 static_assert(B16_BIAS_FLOATS * 4 <= LDS_W0, "bias table");
 static_assert(LDS_TOTAL <= 160 * 1024 && NUM_CHUNKS % 2 == 0, "LDS budget / parity");
 
+static_assert(ACT_TILE_PTS == TILE_PTS && MASK_TILE_PTS == TILE_PTS, "activation blocks and mask tiles are the kernel's tiles");
+
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) void lds_void;
 template <class T>
@@ -119,11 +121,9 @@ struct State {
     // training forward only (SAVE): where this lane's activations go
     char* acts;
     long long P;
-    long long tile_base;              // first point of the tile (uniform)
-    int loff[NCB];                    // byte offset of this lane's 4 features inside the tile's [256, 256] bf16
-                                      // rows: local_row * 512 + (lane>>4) * 8; LOFF_INVALID past the end
-    int tile_rows;                    // points of this tile that exist (uniform)
-    int goff;                         // swapped_goff(lane>>4): this lane's 16 bytes inside a 64-byte fragment row
+    long long tile;                   // tile index (uniform)
+    int loff[NCB];                    // block_lane_offset(lane>>4, point in tile): this lane's granule of
+                                      // fragment 0 in the tile's activation block; LOFF_INVALID past the end
     unsigned mb[NCB][2];              // ReLU mask bits being collected [column block][pair group]
     long long mask_tile;              // byte offset of this tile's dword 0 of layer 0 (nerf_layout::mask_offset_bytes), uniform
 };
@@ -177,22 +177,19 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
             // the fragment is complete: write this lane's 2 x 4 features of layer L's output
             // (row-major [P, width] bf16; features 32Q+4g.. and 32Q+16+4g..) for the backward pass
             if (j2 == 3) {
-                // range-checked buffer stores over (layer, tile): unconditional, so the number of
-                // vector-memory instructions per chunk is a constant (chunk_barrier) and lanes past
-                // the last point fall outside num_records
-                constexpr int RB = act_width(L) * 2;
-                char* tb = st.acts + (act_offset_bytes(L, st.P) + st.tile_base * RB);
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, st.tile_rows * RB, 0x00020000);
-                const int vo = RB == 512 ? st.loff[cb] : (st.loff[cb] + st.goff) >> 1;   // rows of L9 are half as long
-                // The lane holds two 8-byte pieces 32 bytes apart (features 32Q+4g.. and 32Q+16+4g..).
-                // v_permlane16_swap trades one piece with the neighbouring 16-lane row (g ^ 1): even g
+                // Buffer stores into this (layer, tile)'s point-blocked block (nerf_layout.h),
+                // unconditional so the vector-memory instruction count per chunk is a constant
+                // (chunk_barrier); lanes past the last point carry an offset outside num_records.
+                // The lane holds two 8-byte pieces (features 32Q+4g.. and 32Q+16+4g..):
+                // v_permlane16_swap trades one with the neighbouring 16-lane row (g ^ 1) -- even g
                 // ends up with [its first piece | g+1's first piece], odd g with [g-1's second piece |
-                // its second piece] -- 16 contiguous bytes each, one store instead of two (the
-                // epilogue is store-issue-bound: cdna_hip_programming.md T21).  loff carries the
-                // swapped position: g -> byte 0, 32, 16, 48 of the 64-byte group for g = 0, 1, 2, 3.
+                // its second piece], i.e. one whole 16-byte granule (chunk 4Q + swapped_chunk(g)).
+                // The 16 lanes of a quarter-wave then write 256 contiguous bytes.
+                char* tb = st.acts + (act_offset_bytes(L, st.P) + st.tile * ACT_BLOCK_BYTES);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)ACT_BLOCK_BYTES, 0x00020000);
                 const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
                 const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs, vo, 64 * Q, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs, st.loff[cb], Q * 16384, 0);
             }
             if constexpr (D.relu != 0) {
                 // ReLU mask for the backward pass: one bit per feature (post-ReLU bf16 != 0), collected
@@ -352,7 +349,7 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
     for (int cb = 0; cb < NCB; ++cb) {
         long long p = tile_base + c.wave * (16 * NCB) + cb * 16 + col;
         const bool valid = p < a.P;
-        st.loff[cb] = valid ? (c.wave * (16 * NCB) + cb * 16 + col) * 512 + swapped_goff(g) : LOFF_INVALID;
+        st.loff[cb] = valid ? block_lane_offset(g, c.wave * (16 * NCB) + cb * 16 + col) : LOFF_INVALID;
         if (!valid) p = a.P - 1;
         PointIn pt;
         if constexpr (RAYS) {
@@ -434,9 +431,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
         st.acts = reinterpret_cast<char*>(a.acts);
         st.P = a.P;
         st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
-        st.tile_base = tile_base;
-        st.tile_rows = (int)(a.P - tile_base < TILE_PTS ? a.P - tile_base : TILE_PTS);
-        st.goff = swapped_goff(c.lane >> 4);
+        st.tile = tile;
         stage_inputs<RAYS>(c, a, tile_base, st);
 
         run_layer<0, SAVE>(c, st, st.X, st.X);

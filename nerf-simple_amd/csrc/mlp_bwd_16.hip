@@ -63,6 +63,8 @@ constexpr int LDS_W0 = 0;
 constexpr int LDS_TOTAL = 2 * LDS_WBUF;
 static_assert(NUM_CHUNKS % 2 == 0, "buffer parity must repeat per tile");
 
+static_assert(ACT_TILE_PTS == TILE_PTS && MASK_TILE_PTS == TILE_PTS, "activation blocks and mask tiles are the kernel's tiles");
+
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) void lds_void;
 template <class T>
@@ -86,10 +88,8 @@ struct State {
     ex8 bx_rgb[2], bx_sig[2];       // custom k-steps built from d_raw
     const char* acts;
     char* dys;
-    long long P, tile_base;
-    int loff[2];                    // local_row * 512 + (lane>>4) * 8 inside the tile's rows, LOFF_INVALID past the end
-    int tile_rows;                  // points of this tile that exist (uniform)
-    int goff;
+    long long P, tile;
+    int loff[2];                    // block_lane_offset(lane>>4, point in tile), LOFF_INVALID past the end
 };
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -139,15 +139,13 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
     w[j2] = pack2(v0, v1);
     dst[cb][Q] = __builtin_bit_cast(ex8, w);
     if (j2 == 3) {
-        // range-checked buffer stores over (layer, tile), unconditional: see chunk_barrier
-        constexpr int RB = act_width(LOUT) * 2;
-        char* tb = st.dys + (act_offset_bytes(LOUT, st.P) + st.tile_base * RB);
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, st.tile_rows * RB, 0x00020000);
-        const int vo = RB == 512 ? st.loff[cb] : (st.loff[cb] + st.goff) >> 1;       // rows of dY9 are half as long
-        // one 16-byte store after trading 8-byte pieces with lane group g ^ 1 (forward epilogue_piece)
+        // one 16-byte granule per lane into the (layer, tile) block of dY, after trading 8-byte
+        // pieces with lane group g ^ 1; unconditional buffer store (forward epilogue_piece)
+        char* tb = st.dys + (act_offset_bytes(LOUT, st.P) + st.tile * ACT_BLOCK_BYTES);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)ACT_BLOCK_BYTES, 0x00020000);
         const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs, vo, 64 * Q, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs, st.loff[cb], Q * 16384, 0);
     }
 }
 
@@ -280,16 +278,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(Bwd
         st.acts = a.acts;
         st.dys = a.dys;
         st.P = a.P;
-        st.goff = swapped_goff(g);
         st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
-        st.tile_base = tile_base;
-        st.tile_rows = (int)(a.P - tile_base < TILE_PTS ? a.P - tile_base : TILE_PTS);
+        st.tile = tile;
         load_mask<bwd_desc(0).mask_act>(st, st.mk[0]);
         const __bf16 z = (__bf16)0.f;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             const long long p = tile_base + c.wave * 32 + cb * 16 + col;
-            st.loff[cb] = p < a.P ? (c.wave * 32 + cb * 16 + col) * 512 + swapped_goff(g) : LOFF_INVALID;
+            st.loff[cb] = p < a.P ? block_lane_offset(g, c.wave * 32 + cb * 16 + col) : LOFF_INVALID;
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
             if (p < a.P) d = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);
             // custom k-steps: lane group 0 carries drgb (elements 0..2) / dsigma (element 0)

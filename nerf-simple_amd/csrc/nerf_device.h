@@ -43,9 +43,13 @@ struct MlpArgs {
 // stalls every chunk on the round trip of the stores just issued.  N is a compile-time count;
 // tests/test_library_cpu.py::test_counted_vmcnt_waits checks it against the generated ISA.
 constexpr int LOFF_INVALID = 0x40000000;      // lane offset of a point past the end: out of any buffer range
-// byte offset of lane group g's 16 bytes inside a 64-byte fragment row once the 8-byte pieces
-// have been traded with v_permlane16_swap (mlp_bf16_16.hip epilogue_piece): g = 0,1,2,3 -> 0,32,16,48
-__host__ __device__ constexpr int swapped_goff(int g) { return (g & 1) * 32 + (g >> 1) * 16; }
+// Which of the 4 feature chunks (16 B = 8 features) of a 32-feature fragment lane group g holds
+// once the 8-byte pieces have been traded with v_permlane16_swap (mlp_bf16_16.hip
+// epilogue_piece): g = 0,1,2,3 -> chunk 0,2,1,3.
+__host__ __device__ constexpr int swapped_chunk(int g) { return (g & 1) * 2 + (g >> 1); }
+// byte offset of (that chunk, point `local` of the tile) inside fragment Q = 0's part of a
+// point-blocked activation block (nerf_layout.h); fragment Q adds Q * 4 chunks = Q * 16 KiB
+__host__ __device__ constexpr int block_lane_offset(int g, int local) { return swapped_chunk(g) * 4096 + local * 16; }
 
 template <int N>
 __device__ __forceinline__ void chunk_barrier() {

@@ -264,11 +264,29 @@ NL_HD constexpr int bwd_layer_off_kib(int b) {
 constexpr int BWD_WEIGHT_KIB = bwd_layer_off_kib(NUM_BWD);           // 1112
 constexpr long long BWD_IMAGE_BYTES = (long long)BWD_WEIGHT_KIB * 1024;
 
-// saved forward activations (bf16, row-major [P, width]): index = internal layer
-// L0..L7 post-ReLU (256), L8 = h9 linear (256), L9 = c post-ReLU (128)
+// saved forward activations (bf16), index = internal layer: L0..L7 post-ReLU (256 features),
+// L8 = h9 linear (256), L9 = c post-ReLU (128).  Layout "point-blocked": per layer, per tile of
+// 256 points, a 128 KiB block [feature chunk c = f/8 (32)][point in tile (256)][8 bf16 = 16 B].
+// The MLP kernels hold a point per lane, so the 16 lanes of a quarter-wave write 16 consecutive
+// 16-byte granules of one chunk: 256 contiguous bytes per quarter-wave instead of 16 rows (the
+// row-major form cost 64 separate L2 write requests per store instruction and made the training
+// kernels store-issue-bound).  The dW kernel (dw_gemm.hip) reads 32-point slabs of a block with
+// LDS-DMA, 256 contiguous bytes per quarter-wave as well.  Granules of points >= P are never
+// written nor read.
 NL_HD constexpr int act_width(int L) { return L == 9 ? 128 : 256; }
-NL_HD constexpr long long act_offset_bytes(int L, long long P) { return (long long)L * P * 512; }
-NL_HD constexpr long long acts_bf16_bytes(long long P) { return 9 * P * 512 + P * 256; }
+constexpr int ACT_TILE_PTS = 256;
+constexpr long long ACT_BLOCK_BYTES = 256 * 512;                        // one (layer, tile) block
+NL_HD constexpr long long act_tiles(long long P) { return (P + ACT_TILE_PTS - 1) / ACT_TILE_PTS; }
+NL_HD constexpr long long act_layer_stride(long long P) { return act_tiles(P) * ACT_BLOCK_BYTES; }
+NL_HD constexpr long long act_offset_bytes(int L, long long P) { return (long long)L * act_layer_stride(P); }
+// byte offset of feature f of point p inside layer L
+NL_HD constexpr long long act_elem_offset(int L, long long p, int f, long long P) {
+    return act_offset_bytes(L, P) + (p / ACT_TILE_PTS) * ACT_BLOCK_BYTES
+         + ((long long)(f / 8) * ACT_TILE_PTS + p % ACT_TILE_PTS) * 16 + (f % 8) * 2;
+}
+NL_HD constexpr long long acts_bf16_bytes(long long P) { return 10 * act_layer_stride(P); }
+// saved backward pre-activation gradients dY (bf16): same blocks, dY[L] has the width of layer L's output
+
 // ReLU masks of the saved activations, one bit per feature, in the MLP kernels' own register
 // layout so the forward writes and the backward reads them as coalesced dwords: per (layer L,
 // tile of 256 points) 4 dwords x 512 threads.  Thread (wave, lane) holds, for its column block
@@ -282,8 +300,6 @@ NL_HD constexpr long long mask_offset_bytes(int L, long long tile, int dword, lo
     return mask_region_offset(P) + (((long long)L * mask_tiles(P) + tile) * 4 + dword) * 2048;   // + tid * 4
 }
 NL_HD constexpr long long acts_total_bytes(long long P) { return acts_bf16_bytes(P) + 10 * mask_tiles(P) * 8192; }
-// saved backward pre-activation gradients dY (bf16, row-major), same indexing:
-// dY[L] has the width of layer L's output
 
 // ---- packed f32 image -----------------------------------------------------
 // 16-row output tiles (mfma_f32_16x16x4f32).  chunk = (layer, t): K/4 k-steps

@@ -181,7 +181,8 @@ def test_training_forward_relu_mask_bits(dev, synthetic):
     """The ReLU mask bits the training forward appends to the saved activations (read by the
     backward dX chain instead of the activations) decode, by the layout documented in
     csrc/nerf_layout.h, to exactly `saved bf16 activation != 0` -- for every ReLU layer, with a
-    ragged last tile (600 points = 2 full tiles + 88 points)."""
+    ragged last tile (600 points = 2 full tiles + 88 points).  The activations themselves are
+    decoded from their point-blocked layout and checked against the torch forward (bf16 budget)."""
     from nerf_simple_amd import _lib
     from nerf_simple_amd.utils.nets import Nerf
     from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
@@ -189,7 +190,7 @@ def test_training_forward_relu_mask_bits(dev, synthetic):
     net = Nerf().to(dev)
     net.load_state_dict({k: torch.as_tensor(v) for k, v in synthetic.synthetic_state_dict(5, "structured").items()})
     pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
-    rays = camera_rays([pose], [5, 5, synthetic.focal_from_fov(5)]).to(dev)            # 25 rays
+    rays = camera_rays([pose], [5, 5, synthetic.focal_from_fov(5)]).float().contiguous().to(dev)   # 25 rays (the C ABI takes fp32)
     B, N = rays.shape[0], 24
     P = B * N                                                                        # 600
     u = torch.rand(B, N, generator=torch.Generator().manual_seed(4)).to(dev)
@@ -205,7 +206,7 @@ def test_training_forward_relu_mask_bits(dev, synthetic):
     torch.cuda.synchronize()
     host = acts.cpu().numpy()
     ntiles = (P + 255) // 256
-    region = 9 * P * 512 + P * 256
+    region = 10 * ntiles * 256 * 512        # point-blocked bf16 activations: 10 layers x tiles x 128 KiB
     assert nbytes == region + 10 * ntiles * 8192
     masks = host[region:].view(np.uint32).reshape(10, ntiles, 4, 512)               # [layer, tile, dword, thread]
     # thread (wave, lane), column block cb, pair Q, word j, half e  ->  (point, feature, dword, bit)
@@ -214,7 +215,9 @@ def test_training_forward_relu_mask_bits(dev, synthetic):
     checked = 0
     for L in (0, 1, 2, 3, 4, 5, 6, 7, 9):
         width = 128 if L == 9 else 256
-        a = host[L * P * 512: L * P * 512 + P * width * 2].view(np.uint16).reshape(P, width)
+        # layer L, tile t: [feature chunk f/8 (32)][point in tile (256)][8 bf16]  ->  a[p, f]
+        blk = host[L * ntiles * 131072: (L + 1) * ntiles * 131072].view(np.uint16).reshape(ntiles, 32, 256, 8)
+        a = blk.transpose(0, 2, 1, 3).reshape(ntiles * 256, 256)[:P, :width]
         for tile in range(ntiles):
             for cb in range(2):
                 pt = tile * 256 + wave * 32 + cb * 16 + (lane & 15)
@@ -229,6 +232,22 @@ def test_training_forward_relu_mask_bits(dev, synthetic):
                             checked += int(ok.sum())
         assert 0.02 < (a != 0).mean() < 0.98, L          # the masks are not trivial
     assert checked == P * (8 * 256 + 128)
+    # the decoded layer-0 activations are relu(layers_0.0(gamma(x))) of the same sample points
+    from nerf_simple_amd.utils.xyz import positional_encoder
+    o, dd = rays[:, :3], rays[:, 3:]
+    pts = (o[:, None, :] + ts[..., None] * dd[:, None, :]).reshape(-1, 3)
+    posx, _ = positional_encoder(torch.cat([pts, dd[:, None, :].expand(B, N, 3).reshape(-1, 3)], dim=-1).contiguous())
+    sd = net.state_dict()
+    want0 = torch.relu(posx.float() @ sd["layers_0.0.weight"].float().T + sd["layers_0.0.bias"].float()).cpu()
+    blk0 = host[:ntiles * 131072].view(np.uint16).reshape(ntiles, 32, 256, 8).transpose(0, 2, 1, 3).reshape(-1, 256)[:P]
+    got0 = torch.from_numpy(blk0.astype(np.int32) << 16).view(torch.float32)
+    err = (got0 - want0).abs()
+    badmask = err > 2e-2 * float(want0.abs().max())
+    if bool(badmask.any()):
+        rows, cols = torch.nonzero(badmask, as_tuple=True)
+        print("layer-0 activation mismatches:", int(badmask.sum()), "rows", sorted(set(rows.tolist()))[:40],
+              "cols", sorted(set(cols.tolist()))[:40])
+    assert not bool(badmask.any())
 
 
 def test_fused_adam_matches_torch(dev, golden, synthetic):

@@ -139,8 +139,8 @@ def test_abi_argument_errors(lib):
     assert lib.nerf_amd_generate_rays(one, 10, 10, ctypes.c_float(0.0), 0, 10, one, null) == EINVAL    # f <= 0
     assert lib.nerf_amd_mlp_backward(null, one, one, one, 16, null) == EINVAL
     assert lib.nerf_amd_param_gradients(one, one, one, one, one, one, null, 16, null) == EINVAL
-    # bf16 activations + ReLU mask bits (10 layers x ceil(P/256) tiles x 8 KiB)
-    assert lib.nerf_amd_train_activation_bytes(1000) == 1000 * (9 * 512 + 256) + 10 * 4 * 8192
+    # point-blocked bf16 activations (10 layers x ceil(P/256) tiles x 128 KiB) + ReLU mask bits (.. x 8 KiB)
+    assert lib.nerf_amd_train_activation_bytes(1000) == 10 * 4 * (131072 + 8192)
     assert lib.nerf_amd_packed_bytes(3) == 1112 * 1024
     assert lib.nerf_amd_packed_bytes(2) == 1172 * 1024 + 2464 * 4
 
