@@ -80,24 +80,61 @@ __global__ void sample_encode_kernel(MlpArgs a, float* __restrict__ posx, float*
 
 // The same front end for the fused training path: bf16 outputs padded to the dW GEMM's
 // operand widths, posx [P,64] (col 63 = 0) and posd [P,32] (cols 27..31 = 0).
-__global__ void sample_encode_bf16_kernel(MlpArgs a, __bf16* __restrict__ posx, __bf16* __restrict__ posd) {
-    constexpr int C = 64 + 32;
-    const long long total = a.P * C;
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        const long long p = e / C;
-        int col = (int)(e - p * C);
-        const PointIn pt = fetch_point_rays(a, p);
-        if (col == 0 && a.ts_out) a.ts_out[p] = pt.t;
-        const float xyz[3] = {pt.x, pt.y, pt.z}, dd[3] = {pt.d1, pt.d2, pt.d3};
-        if (col < 64) {
-            const float v = col < 3 ? xyz[col] : col < 63 ? enc_value(xyz[(col - 3) / 20], (col - 3) % 20) : 0.f;
-            posx[p * 64 + col] = (__bf16)v;
-        } else {
-            col -= 64;
-            const float v = col < 3 ? dd[col] : col < 27 ? enc_value(dd[(col - 3) / 8], (col - 3) % 8) : 0.f;
-            posd[p * 32 + col] = (__bf16)v;
+// One thread per point: the point is fetched once, the 84 sines / cosines come from the
+// hardware v_sin / v_cos on arguments in revolutions (to_revolutions + sincos_rev_fast, the
+// encoder of the bf16 MLP kernels, ~1e-6 abs -- far inside bf16), and each thread writes its two
+// rows as 16-byte stores.
+typedef __bf16 enc_bf16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void sample_encode_bf16_kernel(MlpArgs a, __bf16* __restrict__ posx,
+                                                                 __bf16* __restrict__ posd) {
+    const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (p >= a.P) return;
+    const PointIn pt = fetch_point_rays(a, p);
+    if (a.ts_out) a.ts_out[p] = pt.t;
+    {
+        __bf16 row[64];
+        const float xyz[3] = {pt.x, pt.y, pt.z};
+#pragma unroll
+        for (int cd = 0; cd < 3; ++cd) {
+            row[cd] = (__bf16)xyz[cd];
+            const TwoF q = to_revolutions(xyz[cd]);
+#pragma unroll
+            for (int l = 0; l < 10; ++l) {
+                float sn, cs;
+                sincos_rev_fast(q, __builtin_amdgcn_ldexpf(1.0f, l), sn, cs);
+                row[3 + 20 * cd + 2 * l] = (__bf16)sn;
+                row[3 + 20 * cd + 2 * l + 1] = (__bf16)cs;
+            }
         }
+        row[63] = (__bf16)0.f;
+        enc_bf16x8* dst = reinterpret_cast<enc_bf16x8*>(posx + p * 64);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            dst[k] = enc_bf16x8{row[8 * k], row[8 * k + 1], row[8 * k + 2], row[8 * k + 3],
+                                row[8 * k + 4], row[8 * k + 5], row[8 * k + 6], row[8 * k + 7]};
+    }
+    {
+        __bf16 row[32];
+        const float dd[3] = {pt.d1, pt.d2, pt.d3};
+#pragma unroll
+        for (int cd = 0; cd < 3; ++cd) {
+            row[cd] = (__bf16)dd[cd];
+            const TwoF q = to_revolutions(dd[cd]);
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                float sn, cs;
+                sincos_rev_fast(q, __builtin_amdgcn_ldexpf(1.0f, l), sn, cs);
+                row[3 + 8 * cd + 2 * l] = (__bf16)sn;
+                row[3 + 8 * cd + 2 * l + 1] = (__bf16)cs;
+            }
+        }
+#pragma unroll
+        for (int k = 27; k < 32; ++k) row[k] = (__bf16)0.f;
+        enc_bf16x8* dst = reinterpret_cast<enc_bf16x8*>(posd + p * 32);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            dst[k] = enc_bf16x8{row[8 * k], row[8 * k + 1], row[8 * k + 2], row[8 * k + 3],
+                                row[8 * k + 4], row[8 * k + 5], row[8 * k + 6], row[8 * k + 7]};
     }
 }
 
@@ -135,7 +172,7 @@ extern "C" int nerf_amd_launch_sample_encode(const MlpArgs* args, float* posx, f
 extern "C" int nerf_amd_launch_sample_encode_bf16(const MlpArgs* args, void* posx64, void* posd32, hipStream_t stream) {
     (void)hipGetLastError();
     if (args->P == 0) return 0;
-    hipLaunchKernelGGL(sample_encode_bf16_kernel, dim3(grid_for(args->P * 96)), dim3(256), 0, stream, *args,
+    hipLaunchKernelGGL(sample_encode_bf16_kernel, dim3((unsigned)((args->P + 255) / 256)), dim3(256), 0, stream, *args,
                        reinterpret_cast<__bf16*>(posx64), reinterpret_cast<__bf16*>(posd32));
     return (int)hipGetLastError();
 }

@@ -143,9 +143,7 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
         // pieces with lane group g ^ 1; unconditional buffer store (forward epilogue_piece)
         char* tb = st.dys + (act_offset_bytes(LOUT, st.P) + st.tile * ACT_BLOCK_BYTES);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)ACT_BLOCK_BYTES, 0x00020000);
-        const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
-        const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{s0[0], s1[0], s0[1], s1[1]}, rs, st.loff[cb], Q * 16384, 0);
+        store_granule(rs, st.loff[cb], Q * 16384, w);
     }
 }
 

@@ -51,6 +51,25 @@ __host__ __device__ constexpr int swapped_chunk(int g) { return (g & 1) * 2 + (g
 // point-blocked activation block (nerf_layout.h); fragment Q adds Q * 4 chunks = Q * 16 KiB
 __host__ __device__ constexpr int block_lane_offset(int g, int local) { return swapped_chunk(g) * 4096 + local * 16; }
 
+// The epilogue's granule store.  w = {first piece (2 dwords), second piece (2 dwords)} of this lane;
+// v_permlane16_swap trades one piece with lane group g ^ 1 (see mlp_bf16_16.hip epilogue_piece) and
+// the lane stores 16 contiguous bytes at voffset + soffset of the (layer, tile) block.
+//
+// Hazard found on MI355X (tools/stress_train.py; it cost NaNs in dY9 in every repetition of the
+// backward): a buffer_store_dwordx4 whose soffset is an SGPR, followed IMMEDIATELY by a VALU write
+// of its first data register, stored that new value for the last lanes of each 16-lane row.
+// hipcc pads this store-data write-after-read case with s_nop only when soffset is not a
+// register (its hazard table says a register soffset delays the next instruction enough), so the
+// padding is explicit here: the trailing asm keeps the four data registers live past the store
+// and supplies the wait states.
+__device__ __forceinline__ void store_granule(__amdgpu_buffer_rsrc_t rs, int voffset, int soffset, u32x4 w) {
+    const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(w[1], w[3], false, false);
+    const unsigned o0 = s0[0], o1 = s1[0], o2 = s0[1], o3 = s1[1];
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{o0, o1, o2, o3}, rs, voffset, soffset, 0);
+    asm volatile("s_nop 1" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void chunk_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");

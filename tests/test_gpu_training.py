@@ -250,6 +250,89 @@ def test_training_forward_relu_mask_bits(dev, synthetic):
     assert not bool(badmask.any())
 
 
+def test_sample_encode_bf16_matches_fp32_encoder(dev, synthetic):
+    """The training front end (one thread per point, hardware sin / cos in revolutions, bf16 rows
+    padded to 64 / 32 columns for the dW kernel) against the fp32 parity encoder
+    nerf_amd_sample_encode on the same rays and sample positions: within one bf16 rounding
+    (values are in [-1, 1] apart from the raw coordinates), pad columns exactly zero."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    lib = _lib.lib()
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
+    rays = camera_rays([pose], [9, 7, synthetic.focal_from_fov(9)]).float().contiguous().to(dev)
+    B, N = rays.shape[0], 40                                          # 2520 points: a ragged last block
+    u = torch.rand(B, N, generator=torch.Generator().manual_seed(8)).to(dev)
+    tbins = torch.linspace(2, 6, N + 1).to(dev)
+    P = B * N
+    posx = torch.empty(P, 63, device=dev); posd = torch.empty(P, 27, device=dev); ts = torch.empty(B, N, device=dev)
+    _lib.check(lib.nerf_amd_sample_encode(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tbins), 0, 0, 0,
+                                          _lib.ptr(posx), _lib.ptr(posd), _lib.ptr(ts), B, N, _lib.stream_ptr(dev)),
+               "nerf_amd_sample_encode")
+    px = torch.full((P, 64), 7.0, dtype=torch.bfloat16, device=dev)
+    pd = torch.full((P, 32), 7.0, dtype=torch.bfloat16, device=dev)
+    ts2 = torch.empty(B, N, device=dev)
+    _lib.check(lib.nerf_amd_sample_encode_bf16(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tbins), 0, 0, 0,
+                                               _lib.ptr(px), _lib.ptr(pd), _lib.ptr(ts2), B, N, _lib.stream_ptr(dev)),
+               "nerf_amd_sample_encode_bf16")
+    torch.cuda.synchronize()
+    assert torch.equal(ts, ts2)
+    assert float(px[:, 63].abs().max()) == 0 and float(pd[:, 27:].abs().max()) == 0
+    for got, want in ((px[:, :63].float(), posx), (pd[:, :27].float(), posd)):
+        tol = 2.0 ** -8 * want.abs().clamp(min=1.0) + 2e-6          # half an ulp of bf16 is 2^-9 relative
+        assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
+
+
+def test_training_kernels_are_deterministic(dev, synthetic):
+    """forward_train and mlp_backward have no atomics: repeated on identical inputs, every output
+    byte must repeat (a difference is a race or an unpadded hardware hazard -- this is the test
+    that exposes the store-data hazard described at store_granule in csrc/nerf_device.h);
+    param_gradients (float atomics) must repeat to rounding."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    lib = _lib.lib()
+    net = Nerf().to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
+    rays = camera_rays([pose], [32, 32, synthetic.focal_from_fov(32)]).float().contiguous().to(dev)
+    B, N = rays.shape[0], 64
+    P = B * N                                                         # 65536 points: every CU gets a tile
+    u = torch.rand(B, N, generator=torch.Generator().manual_seed(4)).to(dev)
+    tbins = torch.linspace(2, 6, N + 1).to(dev)
+    packed, image = net.packed_weights(_lib.BF16), net.packed_weights(_lib.BF16_BWD)
+    st = _lib.stream_ptr(dev)
+    nb = int(lib.nerf_amd_train_activation_bytes(P))
+    g = torch.randn(P, 4, generator=torch.Generator().manual_seed(5)).to(dev) * 1e-3
+    posx = torch.empty(P, 64, dtype=torch.bfloat16, device=dev)
+    posd = torch.empty(P, 32, dtype=torch.bfloat16, device=dev)
+    ts = torch.empty(B, N, device=dev)
+    _lib.check(lib.nerf_amd_sample_encode_bf16(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tbins), 0, 0, 0, _lib.ptr(posx),
+                                               _lib.ptr(posd), _lib.ptr(ts), B, N, st), "nerf_amd_sample_encode_bf16")
+    scratch = torch.empty(int(lib.nerf_amd_param_gradients_scratch_bytes(P)), dtype=torch.uint8, device=dev)
+
+    def run(acts_in=None):
+        raw = torch.zeros(B, N, 4, device=dev)
+        t2 = torch.zeros(B, N, device=dev)
+        acts = torch.zeros(nb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.nerf_amd_mlp_forward_train(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tbins), _lib.ptr(packed), 0, 0, 0,
+                                                  _lib.ptr(raw), _lib.ptr(t2), _lib.ptr(acts), B, N, st), "forward_train")
+        src = acts if acts_in is None else acts_in
+        dys = torch.zeros(nb, dtype=torch.uint8, device=dev)
+        _lib.check(lib.nerf_amd_mlp_backward(_lib.ptr(g), _lib.ptr(image), _lib.ptr(src), _lib.ptr(dys), P, st), "backward")
+        flat = torch.empty(int(lib.nerf_amd_param_count()), device=dev)
+        _lib.check(lib.nerf_amd_param_gradients(_lib.ptr(g), _lib.ptr(src), _lib.ptr(dys), _lib.ptr(posx), _lib.ptr(posd),
+                                                _lib.ptr(scratch), _lib.ptr(flat), P, st), "param_gradients")
+        return raw, acts, dys, flat
+
+    raw0, acts0, dys0, flat0 = run()
+    assert torch.isfinite(flat0).all() and float(flat0.abs().max()) > 0
+    for _ in range(25):
+        raw, acts, dys, flat = run(acts0)
+        assert torch.equal(raw, raw0) and torch.equal(acts, acts0)
+        assert torch.equal(dys, dys0)
+        assert float((flat - flat0).abs().max()) <= 1e-5 * float(flat0.abs().max())
+
+
 def test_fused_adam_matches_torch(dev, golden, synthetic):
     """N3: optim.FusedAdam == torch.optim.Adam (reference train.py:43,55-57) -- on golden G6 for the
     first step, and over several decayed steps of the fused bf16 path against torch's optimizer."""

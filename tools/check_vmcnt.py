@@ -7,6 +7,9 @@ costs time.  This walks the gfx950 assembly of a kernel: for every inline-asm
 `s_waitcnt vmcnt(N)` directly in front of an `s_barrier`, the vector-memory instructions
 between the preceding `... lds` DMA instruction and the wait are counted and compared with N.
 
+It also scans for the store-data hazard found on MI355X (csrc/nerf_device.h store_granule): a
+wide store whose data registers the next instruction overwrites.
+
 usage: python tools/check_vmcnt.py file.hip [more.hip ...]   (needs hipcc; no GPU)
 """
 import os
@@ -69,6 +72,32 @@ def check_kernel(lines):
     return checked, bad
 
 
+# data registers: first operand of a buffer store, second of a global store
+STORE128 = re.compile(r"^\s*(?:buffer_store_dwordx[34]\s+|global_store_dwordx[34]\s+v(?:\[\d+:\d+\]|\d+),\s*)()v\[(\d+):(\d+)\]")
+VALU_DST = re.compile(r"^\s*v_\w+\s+v(?:\[(\d+):(\d+)\]|(\d+))")
+
+
+def check_store_data_hazard(lines):
+    """Wide stores whose data registers are written by the very next instruction (the MI355X
+    store-data hazard documented at store_granule in csrc/nerf_device.h).  -> (stores, offenders)"""
+    stores, bad = 0, []
+    real = [l.split(";")[0].rstrip() for l in lines]
+    real = [l for l in real if l.strip() and not l.strip().startswith((".", "#"))]
+    for i, text in enumerate(real[:-1]):
+        m = STORE128.match(text)
+        if not m:
+            continue
+        stores += 1
+        lo, hi = int(m.group(2)), int(m.group(3))
+        w = VALU_DST.match(real[i + 1])
+        if w:
+            d0 = int(w.group(1) if w.group(1) is not None else w.group(3))
+            d1 = int(w.group(2)) if w.group(2) is not None else d0
+            if d0 <= hi and d1 >= lo:
+                bad.append((text.strip(), real[i + 1].strip()))
+    return stores, bad
+
+
 def assemble(src, extra=()):
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
@@ -83,6 +112,11 @@ def check_source(src, extra=()):
     return {k: check_kernel(v) for k, v in kernels_of(assemble(src, extra)).items()}
 
 
+def check_source_stores(src, extra=()):
+    """-> {kernel: (wide stores, offenders)}"""
+    return {k: check_store_data_hazard(v) for k, v in kernels_of(assemble(src, extra)).items()}
+
+
 if __name__ == "__main__":
     rc = 0
     for src in sys.argv[1:]:
@@ -90,5 +124,8 @@ if __name__ == "__main__":
             print(f"{os.path.basename(src)} {k[:70]}: {n} counted waits, {len(bad)} mismatches")
             for ln, want, got in bad[:10]:
                 print(f"    line {ln}: vmcnt({want}) but {got} vector-memory instructions follow the DMA")
+            rc |= bool(bad)
+        for k, (n, bad) in check_source_stores(src).items():
+            print(f"{os.path.basename(src)} {k[:70]}: {n} wide stores, {len(bad)} with data overwritten by the next instruction")
             rc |= bool(bad)
     sys.exit(rc)
