@@ -310,6 +310,10 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
     }
 #if defined(NERF_EXP) && NERF_EXP == 3
     // ablation: no chunk barrier (races: results are garbage; timing only)
+#elif defined(NERF_EXP) && NERF_EXP == 5
+    // A/B: the fenced barrier used before chunk_barrier existed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 #else
     // this wave's LDS-DMA pieces (issued first in this chunk) have landed; the stores behind them may fly on
     chunk_barrier<pair_vmem_ops<SAVE>(PL, PQ) + (NT == 4 ? pair_vmem_ops<SAVE>(L, 2 * C) : 0)>();

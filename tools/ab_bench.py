@@ -21,7 +21,7 @@ dev = torch.device("cuda:0")
 net = Nerf(precision="bf16").to(dev)
 net.load_state_dict(synthetic.synthetic_state_dict(0, "structured"))
 pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
-rays = camera_rays([pose], [800, 800, synthetic.focal_from_fov(800)]).to(dev)
+rays = camera_rays([pose], [800, 800, synthetic.focal_from_fov(800)]).float().contiguous().to(dev)   # the C ABI takes contiguous fp32
 B, N = rays.shape[0], 128
 raw = torch.empty(B, N, 4, device=dev)
 ts = torch.empty(B, N, device=dev)
