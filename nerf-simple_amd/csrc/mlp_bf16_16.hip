@@ -434,7 +434,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
         st.P = a.P;
         st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
         st.tile = tile;
+#if defined(NERF_EXP) && NERF_EXP == 6
+        // ablation: the tile prologue (ray loads, RNG, encoding) only for the first tile; timing only
+        if (tile == (long long)blockIdx.x) stage_inputs<RAYS>(c, a, tile_base, st);
+        else { for (int cb_ = 0; cb_ < NCB; ++cb_) st.loff[cb_] = LOFF_INVALID; }
+#else
         stage_inputs<RAYS>(c, a, tile_base, st);
+#endif
 
         run_layer<0, SAVE>(c, st, st.X, st.X);
         run_layer<1, SAVE>(c, st, st.X, st.Y);
