@@ -190,11 +190,11 @@ def main():
                 "fp32": "nerf_mlp_f32_kernel<true>"}[args.precision]
         # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3
         # cannot run inside this process): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 wide-read correction),
-        # 1.6e6 KB + 2 x 37.3e3 KB for the full 81.92 M-sample launch; algorithmic: 20 B/sample written.
+        # 1.6e6 KB + 2 x 31.9e3 KB for the full 81.92 M-sample launch; algorithmic: 20 B/sample written.
         traffic, traffic_src = None, None
         if world == 1 and args.precision == "bf16":
-            traffic = (1.6e6 + 2 * 37.3e3) * 1024
-            traffic_src = "profiles/r01c_bench_rocprofv3_summary.txt (WRITE_SIZE + 2*FETCH_SIZE, same command)"
+            traffic = (1.6e6 + 2 * 31.9e3) * 1024
+            traffic_src = "profiles/r01e_bench_rocprofv3_summary.txt (WRITE_SIZE + 2*FETCH_SIZE, same command)"
         res = {
             "metric": "ray-samples/sec at 800x800x128", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
