@@ -46,21 +46,11 @@ class FusedAdam:
                     p.grad.zero_()
 
     def _flat_grad(self):
-        g0 = self.params[0].grad
         # the fused backward hands out views of ONE flat vector: use it in place
-        if (g0 is not None and g0.untyped_storage().nbytes() >= self.flat.numel() * 4 and
-                g0.storage_offset() == 0 and g0.dtype == torch.float32):
-            base = g0.untyped_storage().data_ptr()
-            off, ok = 0, True
-            for p in self.params:
-                g = p.grad
-                if (g is None or not g.is_contiguous() or g.untyped_storage().data_ptr() != base or
-                        g.storage_offset() != off):
-                    ok = False
-                    break
-                off += p.numel()
-            if ok:
-                return torch.as_strided(g0, (self.flat.numel(),), (1,), 0)
+        from .parallel import flat_grad_view
+        flat = flat_grad_view(self.params)
+        if flat is not None and flat.numel() == self.flat.numel():
+            return flat
         torch.cat([p.grad.reshape(-1).float() for p in self.params], out=self._grad)
         return self._grad
 

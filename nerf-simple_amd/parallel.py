@@ -70,6 +70,29 @@ def render_image_sharded(rays, render_fn, group=None, u=None):
     return full[:, :3], full[:, 3]
 
 
+def flat_grad_view(params):
+    """If the gradients of ``params`` are consecutive views of ONE contiguous fp32 buffer (what
+    the fused backward hands out: nerf_amd_param_gradients writes a single flat vector in
+    state_dict order), return that buffer as a 1-D tensor sharing their memory; else None."""
+    params = list(params)
+    if not params or any(p.grad is None for p in params):
+        return None
+    g0 = params[0].grad
+    if g0.dtype != torch.float32 or not g0.is_contiguous():
+        return None
+    base, off = g0.untyped_storage().data_ptr(), g0.storage_offset()
+    start = off
+    for p in params:
+        g = p.grad
+        if (g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != base or
+                g.storage_offset() != off):
+            return None
+        off += g.numel()
+    if g0.untyped_storage().nbytes() < off * 4:
+        return None
+    return torch.as_strided(g0, (off - start,), (1,), start)
+
+
 def allreduce_gradients(params, group=None):
     """Average gradients over data-parallel replicas with ONE collective: the
     grads are flattened into a single contiguous bucket (2.38 MB for the NeRF
@@ -79,6 +102,11 @@ def allreduce_gradients(params, group=None):
     rank, world = world_info(group)
     params = [p for p in params if p.grad is not None]
     if world == 1 or not params:
+        return
+    flat = flat_grad_view(params)
+    if flat is not None:                       # the fused backward's flat vector: reduce it in place
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= world
         return
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

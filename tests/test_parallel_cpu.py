@@ -59,6 +59,29 @@ def _worker(rank, world, port, job, tmp):
             torch.nn.functional.mse_loss(rgb, gt[lo:hi]).backward()
             parallel.allreduce_gradients(list(params.values()))
             np.savez(os.path.join(tmp, f"grads_{rank}.npz"), **{k: p.grad.numpy() for k, p in params.items()})
+        elif job == "flatgrads":
+            # gradients laid out as the fused backward hands them out: views of ONE flat vector
+            shapes = [(4, 3), (4,), (2, 4), (2,)]
+            params = [torch.zeros(s_, requires_grad=True) for s_ in shapes]
+            flat = torch.arange(sum(int(np.prod(s_)) for s_ in shapes), dtype=torch.float32) * (rank + 1)
+            off = 0
+            for p_, s_ in zip(params, shapes):
+                k = int(np.prod(s_))
+                p_.grad = flat[off:off + k].view(s_)
+                off += k
+            assert parallel.flat_grad_view(params) is not None
+            assert parallel.flat_grad_view(params).data_ptr() == flat.data_ptr()
+            parallel.allreduce_gradients(params)
+            want = torch.arange(flat.numel(), dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+            assert torch.equal(flat, want)                       # reduced in place, no copies
+            assert all(p_.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p_ in params)
+            # and a list that is NOT one buffer takes the bucket path
+            loose = [torch.zeros(3, requires_grad=True), torch.zeros(2, requires_grad=True)]
+            for p_ in loose:
+                p_.grad = torch.full_like(p_, float(rank + 1))
+            assert parallel.flat_grad_view(loose) is None
+            parallel.allreduce_gradients(loose)
+            assert all(bool((p_.grad == sum(range(1, world + 1)) / world).all()) for p_ in loose)
         elif job == "bcast":
             lin = torch.nn.Linear(5, 3)
             with torch.no_grad():
@@ -104,6 +127,11 @@ def test_gradient_allreduce_equals_global_batch(tmp_path, golden):
         else:
             np.testing.assert_allclose(a[k][:16, :16], g[f"gradc/{k}"], rtol=2e-4, atol=1e-7, err_msg=k)
         np.testing.assert_allclose(np.linalg.norm(a[k]), g[f"gnorm/{k}"], rtol=1e-4)
+
+
+def test_gradient_allreduce_in_place_on_flat_vector(tmp_path):
+    """The fused backward's flat gradient vector is all-reduced in place (world 2, gloo)."""
+    _run(2, "flatgrads", tmp_path)
 
 
 def test_broadcast_parameters(tmp_path):
