@@ -216,6 +216,13 @@ int nerf_amd_adam_step(float* params, const float* grads, float* exp_avg, float*
                        int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
                        void* stream);
 
+/* The same update with the step-dependent scalars in DEVICE memory: hyper[6] = {lr, beta1,
+ * beta2, eps, 1 - beta1^step, sqrt(1 - beta2^step)} (fp32).  The launch carries no per-step
+ * argument, so it can sit inside a captured hipGraph replayed every iteration while the host
+ * rewrites `hyper` (training.GraphedTrainStep). */
+int nerf_amd_adam_step_hyper(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                             int64_t n, const float* hyper, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

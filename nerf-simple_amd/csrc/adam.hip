@@ -24,7 +24,33 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         p[i] -= (lr / bc1) * (mi / denom);
     }
 }
+// The same update with its step-dependent scalars read from device memory
+// (hyper = {lr, beta1, beta2, eps, 1 - beta1^t, sqrt(1 - beta2^t)}), so the launch can live
+// inside a captured hipGraph that is replayed with a new learning rate / step count.
+__global__ void adam_hyper_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                  float* __restrict__ v, long long n, const float* __restrict__ hyper) {
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], bc1 = hyper[4], bc2_sqrt = hyper[5];
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
 }  // namespace
+
+extern "C" int nerf_amd_launch_adam_hyper(float* params, const float* grads, float* m, float* v, long long n,
+                                          const float* hyper, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (n == 0) return 0;
+    long long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(adam_hyper_kernel, dim3((unsigned)grid), dim3(256), 0, stream, params, grads, m, v, n, hyper);
+    return (int)hipGetLastError();
+}
 
 extern "C" int nerf_amd_launch_adam(float* params, const float* grads, float* m, float* v, long long n, float lr,
                                     float b1, float b2, float eps, float bc1, float bc2_sqrt, hipStream_t stream) {

@@ -30,6 +30,7 @@ int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, long long, hipStream_t);
+int nerf_amd_launch_adam_hyper(float*, const float*, float*, float*, long long, const float*, hipStream_t);
 int nerf_amd_launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float, float,
                          hipStream_t);
 int nerf_amd_launch_sample_encode_bf16(const MlpArgs*, void*, void*, hipStream_t);
@@ -353,6 +354,14 @@ int nerf_amd_adam_step(float* params, const float* grads, float* exp_avg, float*
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     return nerf_amd_launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1,
                                 (float)sqrt(bc2), S(stream));
+}
+
+int nerf_amd_adam_step_hyper(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,
+                             const float* hyper, void* stream) {
+    if (n < 0) return NERF_AMD_EINVAL;
+    if (n == 0) return 0;
+    if (!params || !grads || !exp_avg || !exp_avg_sq || !hyper) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_adam_hyper(params, grads, exp_avg, exp_avg_sq, n, hyper, S(stream));
 }
 
 }  // extern "C"

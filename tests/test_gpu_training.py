@@ -333,6 +333,42 @@ def test_training_kernels_are_deterministic(dev, synthetic):
         assert float((flat - flat0).abs().max()) <= 1e-5 * float(flat0.abs().max())
 
 
+def test_graphed_train_step_matches_eager(dev, golden, synthetic):
+    """training.GraphedTrainStep (the step captured as hipGraphs: forward .. parameter gradients,
+    then Adam with device-resident hyper-parameters + re-pack) against the eager train_step with
+    FusedAdam on the same rays / jitter / targets, 6 decayed steps: same losses (the dW atomics'
+    order is the only difference), same parameters to Adam's eps-corner statistics, and the packed
+    images follow (inference after training sees the new weights)."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.optim import FusedAdam
+    from nerf_simple_amd.training import train_step, lr_decay_factor, GraphedTrainStep
+    g = golden("train.npz")
+    rays, gt, u, N = t(g["rays"]).to(dev), t(g["gt"]).to(dev), t(g["u"]).to(dev), int(g["N"])
+    decay = lr_decay_factor(5e-4, 4e-4, 10)
+    us = [torch.rand(u.shape, generator=torch.Generator().manual_seed(100 + i)).to(dev) for i in range(6)]
+    runs = []
+    for graphed in (False, True):
+        net = Nerf(precision="bf16").to(dev)
+        net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+        opt = FusedAdam(net, lr=5e-4)
+        if graphed:
+            stepper = GraphedTrainStep(net, opt, rays.shape[0], N)
+            losses = [float(stepper.step(rays, gt, u=us[i], decay=decay)) for i in range(6)]
+            assert opt.step_count == 6
+        else:
+            losses = [float(train_step(net, opt, rays, gt, N, u=us[i], decay=decay)) for i in range(6)]
+        assert abs(opt.param_groups[0]["lr"] - 5e-4 * decay ** 6) < 1e-12
+        with torch.no_grad():
+            probe = net(rays[:8].new_zeros(8, 6) + 0.1).cpu()
+        runs.append((losses, torch.cat([p.detach().reshape(-1) for p in net.parameters()]).cpu(), probe))
+    (la, pa, qa), (lb, pb, qb) = runs
+    assert la[-1] < la[0] and lb[-1] < lb[0]
+    np.testing.assert_allclose(la, lb, rtol=2e-3)
+    d = (pa - pb).abs()
+    assert float(d.max()) <= 6 * 5e-4 and float(d.mean()) <= 1e-5 and float((d > 1e-5).float().mean()) <= 0.06
+    assert float((qa - qb).abs().max()) <= 2e-2 * max(1.0, float(qa.abs().max()))
+
+
 def test_fused_adam_matches_torch(dev, golden, synthetic):
     """N3: optim.FusedAdam == torch.optim.Adam (reference train.py:43,55-57) -- on golden G6 for the
     first step, and over several decayed steps of the fused bf16 path against torch's optimizer."""

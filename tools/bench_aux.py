@@ -72,6 +72,20 @@ if "pcie" in which:        # reference-compatible jitter: one CPU torch.rand(B,N
             dt = timed(lambda: render_nerf(r, net, 128, outputs=("rgb", "disp", "acc")), warm=1, reps=3)
             print(json.dumps({"config": f"3 (parity mode): render_nerf B={B} N=128, jitter drawn on the CPU + PCIe copy",
                               "ms": dt * 1e3, "ray_samples_per_s": B * 128 / dt}))
+if "c5g" in which or "c5" in which:   # config 5 through the captured hipGraphs (training.GraphedTrainStep)
+    from nerf_simple_amd.optim import FusedAdam
+    from nerf_simple_amd.training import GraphedTrainStep
+    for N in (64, 128):
+        net = net_of("bf16")
+        opt = FusedAdam(net, lr=5e-4)
+        rays = generate_rays(pose, [800, 800, synthetic.focal_from_fov(800)], dev)[:4096].contiguous()
+        gt = torch.rand(4096, 3, device=dev)
+        u = torch.rand(4096, N, device=dev)
+        stepper = GraphedTrainStep(net, opt, 4096, N)
+        dt = timed(lambda: stepper.step(rays, gt, u=u), warm=3, reps=10)
+        s = 4096 * N
+        print(json.dumps({"config": f"5: train step 4096 rays x {N} bf16, hipGraph replay (fwd+bwd+FusedAdam+repack)",
+                          "ms": dt * 1e3, "ray_samples_per_s": s / dt, "tflops_fwd_bwd(3x)": 3 * s * FLOP / dt / 1e12}))
 if "c5" in which:          # config 5: training steps, 4096 rays x {64,128}, bf16
     from nerf_simple_amd.optim import FusedAdam
     for N, fused_opt in ((64, True), (128, True), (64, False)):
