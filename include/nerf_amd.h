@@ -216,6 +216,17 @@ int nerf_amd_adam_step(float* params, const float* grads, float* exp_avg, float*
                        int64_t n, float lr, float beta1, float beta2, float eps, int64_t step,
                        void* stream);
 
+/* The reference's jitter draw `torch.rand(B, N)` on torch's CPU default generator
+ * (utils/rendering.py:28-30), continued on the GPU with identical values: MT19937, one 32-bit
+ * output per float32, u = (tempered & 0xFFFFFF) * 2^-24.  state624: the generator's 624 state
+ * words (device memory); next: index of the first unread word of the current block, 0..624
+ * (624 = the block is used up); out[n] receives the next n draws; state_out624 the state words
+ * afterwards (equal to state624 if no new block was needed).  The host side keeps the
+ * generator's counters (utils/rendering.py reference_rand).  One workgroup; ~1 barrier per 624
+ * draws. */
+int nerf_amd_mt19937_uniform(const uint32_t* state624, int next, float* out, int64_t n,
+                             uint32_t* state_out624, void* stream);
+
 /* The same update with the step-dependent scalars in DEVICE memory: hyper[6] = {lr, beta1,
  * beta2, eps, 1 - beta1^step, sqrt(1 - beta2^step)} (fp32).  The launch carries no per-step
  * argument, so it can sit inside a captured hipGraph replayed every iteration while the host

@@ -30,6 +30,7 @@ int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, long long, hipStream_t);
+int nerf_amd_launch_mt19937_uniform(const uint32_t*, int, float*, long long, uint32_t*, hipStream_t);
 int nerf_amd_launch_adam_hyper(float*, const float*, float*, float*, long long, const float*, hipStream_t);
 int nerf_amd_launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float, float,
                          hipStream_t);
@@ -354,6 +355,13 @@ int nerf_amd_adam_step(float* params, const float* grads, float* exp_avg, float*
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     return nerf_amd_launch_adam(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1,
                                 (float)sqrt(bc2), S(stream));
+}
+
+int nerf_amd_mt19937_uniform(const uint32_t* state624, int next, float* out, int64_t n, uint32_t* state_out624,
+                             void* stream) {
+    if (n < 0 || next < 0 || next > 624) return NERF_AMD_EINVAL;
+    if (!state624 || !state_out624 || (n > 0 && !out)) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_mt19937_uniform(state624, next, out, n, state_out624, S(stream));
 }
 
 int nerf_amd_adam_step_hyper(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -1,0 +1,192 @@
+"""The reference's jitter draw, generated on the GPU with the reference's own numbers.
+
+``render_nerf`` in the reference draws ``u = torch.rand(B, N)`` on torch's CPU default
+generator and moves it to the GPU (utils/rendering.py:28-30).  Keeping that contract -- same
+values, same advance of the caller's generator -- used to cost more than the render itself
+(MT19937 on one host core + a 4 B/sample PCIe copy: 247 ms against a 65 ms render at
+800x800x128).  ``reference_rand`` continues the generator's stream on the device instead
+(csrc/host_rng.hip): it uploads the 624 state words, lets one workgroup produce the draws
+straight into HBM, and writes the words and counters back into the generator -- 5 KB each way.
+
+The generator state is torch's ``CPUGeneratorImplState`` byte image (ATen/CPUGeneratorImpl.cpp):
+    0  uint64 seed | 8 int32 left | 12 int32 seeded | 16 uint64 next | 24 uint64 state[624]
+    | 5016 .. normal-distribution cache (untouched)
+with at::mt19937's bookkeeping: a draw first decrements ``left`` and regenerates the block when
+it reaches 0 (then left = 624, next = 0), then returns tempered state[next++].  The layout is
+checked against torch itself before first use (``layout_ok``); if the check fails -- another
+torch version with another layout -- the draw falls back to the reference's own
+``torch.rand(B, N).to(device)``, which is the same numbers by definition.
+Set NERF_AMD_HOST_RNG=1 to force that path.
+"""
+import os
+import struct
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+_N = 624
+_STATE_BYTES = 5056
+_layout_ok = None
+
+
+def _parse(state):
+    b = state.numpy().tobytes()
+    _seed, left, seeded, nxt = struct.unpack_from("<QiiQ", b, 0)
+    words = np.frombuffer(b, dtype="<u8", count=_N, offset=24)
+    return left, seeded, nxt, words
+
+
+def _advance(left, nxt, n):
+    """(left, next, new blocks) after n draws (at::mt19937 bookkeeping)."""
+    avail = left - 1                       # unread words of the current block
+    if n <= avail:
+        return left - n, nxt + n, 0
+    r = n - avail
+    blocks = (r + _N - 1) // _N
+    used = r - (blocks - 1) * _N           # words read from the last new block, 1..624
+    return _N + 1 - used, used, blocks
+
+
+def _patched(state, left, nxt, words32):
+    b = bytearray(state.numpy().tobytes())
+    struct.pack_into("<i", b, 8, int(left))
+    struct.pack_into("<Q", b, 16, int(nxt))
+    if words32 is not None:
+        b[24:24 + 8 * _N] = words32.astype("<u8").tobytes()
+    return torch.frombuffer(b, dtype=torch.uint8).clone()
+
+
+def layout_ok():
+    """Pin the state layout and the bookkeeping against torch itself (CPU only, microseconds):
+    a scratch generator is advanced by torch.rand, and the counters predicted from its previous
+    state by ``_advance`` must match the ones torch reports."""
+    global _layout_ok
+    if _layout_ok is None:
+        try:
+            g = torch.Generator()
+            g.manual_seed(20240229)
+            ok = g.get_state().numel() == _STATE_BYTES
+            for n in (3, 700, 624 - 79, 1300):
+                if not ok:
+                    break
+                left, seeded, nxt, words = _parse(g.get_state())
+                ok = seeded == 1 and 0 <= nxt <= _N and 1 <= left <= _N and int(words.max()) < 2 ** 32
+                torch.rand(n, generator=g)
+                l2, _, n2, w2 = _parse(g.get_state())
+                l1, n1, blocks = _advance(left, nxt, n)
+                ok = ok and (l1, n1) == (l2, n2) and (blocks > 0 or np.array_equal(words, w2))
+            _layout_ok = bool(ok)
+        except Exception:
+            _layout_ok = False
+    return _layout_ok
+
+
+class _Pending:
+    """The state words coming back from the device; ``finish`` writes them into the generator."""
+
+    def __init__(self, state, left, nxt, state_out, event):
+        self.state, self.left, self.nxt, self.state_out, self.event = state, left, nxt, state_out, event
+
+    def finish(self):
+        if self.state_out is None:
+            return
+        dev = self.state_out.device
+        side = torch.cuda.Stream(dev)
+        with torch.cuda.stream(side):          # wait for the generator kernel only, not for the render behind it
+            side.wait_event(self.event)
+            host = self.state_out.to("cpu")
+        side.synchronize()
+        words = host.numpy().view(np.uint32)
+        torch.set_rng_state(_patched(self.state, self.left, self.nxt, words))
+        self.state_out = None
+
+
+def reference_rand(B, N, device):
+    """``torch.rand(B, N).to(device)`` of the reference -- same values, same effect on torch's CPU
+    default generator -- without generating or copying B*N floats on the host.
+    Returns (u [B, N] on ``device``, pending): call ``pending.finish()`` once the launches that
+    follow have been enqueued (it waits for the generator kernel and restores the generator)."""
+    n = int(B) * int(N)
+    if os.environ.get("NERF_AMD_HOST_RNG") == "1" or n == 0 or not layout_ok():
+        return torch.rand(B, N).to(device), _Pending(None, 0, 0, None, None)
+    state = torch.get_rng_state()
+    left, _seeded, nxt, words = _parse(state)
+    new_left, new_next, blocks = _advance(left, nxt, n)
+    lib = _lib.lib()
+    u = torch.empty((B, N), dtype=torch.float32, device=device)
+    words_dev = torch.from_numpy(words.astype(np.uint32).view(np.int32)).to(device)
+    state_out = torch.empty(_N, dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        # first unread word of the current block: 625 - left (624 = block exhausted, as after seeding)
+        _lib.check(lib.nerf_amd_mt19937_uniform(_lib.ptr(words_dev), _N + 1 - int(left), _lib.ptr(u), n,
+                                                _lib.ptr(state_out), _lib.stream_ptr(device)),
+                   "nerf_amd_mt19937_uniform")
+        if blocks == 0:                         # the state words did not change: counters only, no read-back
+            torch.set_rng_state(_patched(state, new_left, new_next, None))
+            return u, _Pending(None, 0, 0, None, None)
+        event = torch.cuda.Event()
+        event.record(torch.cuda.current_stream(device))
+    return u, _Pending(state, new_left, new_next, state_out, event)
+
+
+class ReferenceJitter:
+    """The jitter of CONSECUTIVE render_nerf calls -- the batches of an image driver -- drawn
+    ahead of the renders: the reference draws ``torch.rand(B_k, N)`` inside each call, i.e.
+    consecutive pieces of one stream, so all pieces can be enqueued at once on a side stream
+    (each launch continues from the previous one's state words, device to device) and batch k+1
+    is generated while batch k renders.  ``batch(k)`` makes the current stream wait for piece k
+    and returns it; ``finish()`` restores torch's CPU generator to where the reference's draws
+    would have left it."""
+
+    def __init__(self, batch_rays, N, device):
+        self.device, self.N = device, int(N)
+        self.sizes = [int(b) for b in batch_rays]
+        self.fallback = os.environ.get("NERF_AMD_HOST_RNG") == "1" or not layout_ok() or not self.sizes
+        self.pending = _Pending(None, 0, 0, None, None)
+        if self.fallback:
+            return
+        lib = _lib.lib()
+        state = torch.get_rng_state()
+        left, _seeded, nxt, words = _parse(state)
+        total = sum(self.sizes)
+        cur_stream = torch.cuda.current_stream(device)
+        self.u = torch.empty((total, self.N), dtype=torch.float32, device=device)
+        bufs = [torch.from_numpy(words.astype(np.uint32).view(np.int32)).to(device),
+                torch.empty(_N, dtype=torch.int32, device=device)]
+        self.side = torch.cuda.Stream(device)
+        self.side.wait_stream(cur_stream)                  # the buffers above were made on the current stream
+        self.events, self.offsets = [], []
+        any_blocks, row = False, 0
+        with torch.cuda.device(device), torch.cuda.stream(self.side):
+            for b in self.sizes:
+                n = b * self.N
+                piece = self.u[row:row + b]
+                _lib.check(lib.nerf_amd_mt19937_uniform(_lib.ptr(bufs[0]), _N + 1 - int(left), _lib.ptr(piece), n,
+                                                        _lib.ptr(bufs[1]), _lib.stream_ptr(device)),
+                           "nerf_amd_mt19937_uniform")
+                left, nxt, blocks = _advance(left, nxt, n)
+                any_blocks = any_blocks or blocks > 0
+                bufs.reverse()                              # this launch's output state is the next one's input
+                ev = torch.cuda.Event()
+                ev.record(self.side)
+                self.events.append(ev)
+                self.offsets.append(row)
+                row += b
+        self.u.record_stream(self.side)
+        for t_ in bufs:
+            t_.record_stream(self.side)
+        if any_blocks:
+            self.pending = _Pending(state, left, nxt, bufs[0], self.events[-1])
+        else:
+            torch.set_rng_state(_patched(state, left, nxt, None))
+
+    def batch(self, k):
+        if self.fallback:
+            return torch.rand(self.sizes[k], self.N).to(self.device)
+        torch.cuda.current_stream(self.device).wait_event(self.events[k])
+        return self.u[self.offsets[k]:self.offsets[k] + self.sizes[k]]
+
+    def finish(self):
+        self.pending.finish()

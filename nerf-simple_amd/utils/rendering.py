@@ -18,6 +18,7 @@ import torch
 from tqdm import tqdm
 
 from .. import _lib
+from .host_rng import ReferenceJitter, reference_rand
 from .nets import Nerf
 
 ALL_OUTPUTS = ("rgb", "disp", "alpha", "acc", "w")
@@ -97,6 +98,7 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
 
     flags = 0
     jit = None
+    pending_rng = None
     if ts is not None:
         jit, flags = _lib.require_cuda_f32(ts, "ts").contiguous(), _lib.FLAG_TS_GIVEN
     elif u is not None:
@@ -104,12 +106,17 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
     elif device_rng:
         flags = _lib.FLAG_DEVICE_RNG
     else:
-        jit = torch.rand(B, N).to(dev)        # the reference's single CPU draw per call (:28-30)
+        # the reference's single CPU draw per call (:28-30): same numbers, same advance of torch's
+        # CPU generator, produced on the device (host_rng.py)
+        jit, pending_rng = reference_rand(B, N, dev)
     if jit is not None and tuple(jit.shape) != (B, N):
         raise RuntimeError("u / ts must be [B, N]")
 
     fused = isinstance(net, Nerf) and net._fused_ok()
     training = fused and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
+    if pending_rng is not None and (training or not fused):
+        pending_rng.finish()                  # user / autograd code follows: the generator must be current
+        pending_rng = None
     if training:
         from ..training import render_nerf_autograd
         return render_nerf_autograd(rays, net, N, tn, tf, jit, flags,
@@ -150,6 +157,8 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
             _lib.check(lib.nerf_amd_volume_render(
                 _lib.ptr(raw), _lib.ptr(tsb), _lib.ptr(dn.contiguous()), 3, _lib.ptr(rgb), _lib.ptr(disp),
                 _lib.ptr(alpha), _lib.ptr(acc), _lib.ptr(w), B, N, st), "nerf_amd_volume_render")
+    if pending_rng is not None:
+        pending_rng.finish()                  # the render is enqueued behind it: only the generator kernel is awaited
     return rgb, disp, alpha, acc, w
 
 
@@ -185,14 +194,26 @@ def _render_batched(rays, net, batch_size, N, tn, tf, u, progress, id_base=0, **
     rgb = torch.empty((n, 3), dtype=torch.float32, device=rays.device)
     disp = torch.empty((n,), dtype=torch.float32, device=rays.device)
     starts = range(0, n, batch_size)
-    with torch.no_grad():
-        for s in (tqdm(starts) if progress else starts):
-            e = min(s + batch_size, n)
-            r, d, _, _, _ = render_nerf(rays[s:e], net, N, tn, tf,
-                                        u=None if u is None else u[s:e],
-                                        outputs=("rgb", "disp", "acc"), ray_id0=id_base + s, **kw)
-            rgb[s:e] = torch.clip(r, 0., 1.)
-            disp[s:e] = d
+    # The reference draws each batch's jitter inside render_nerf from the CPU generator: consecutive
+    # pieces of one stream.  For the fused path they are all enqueued now on a side stream, so
+    # batch k+1 is drawn while batch k renders (host_rng.ReferenceJitter); a generic ``net`` keeps
+    # the per-call draw, since its forward may use the generator itself.
+    ahead = None
+    if (u is None and not kw.get("device_rng") and n > 0 and rays.is_cuda
+            and isinstance(net, Nerf) and net._fused_ok()):
+        ahead = ReferenceJitter([min(s + batch_size, n) - s for s in starts], N, rays.device)
+    try:
+        with torch.no_grad():
+            for k, s in enumerate(tqdm(starts) if progress else starts):
+                e = min(s + batch_size, n)
+                uk = ahead.batch(k) if ahead is not None else (None if u is None else u[s:e])
+                r, d, _, _, _ = render_nerf(rays[s:e], net, N, tn, tf, u=uk,
+                                            outputs=("rgb", "disp", "acc"), ray_id0=id_base + s, **kw)
+                rgb[s:e] = torch.clip(r, 0., 1.)
+                disp[s:e] = d
+    finally:
+        if ahead is not None:
+            ahead.finish()
     return rgb, disp
 
 
@@ -288,7 +309,8 @@ def render_view(net, pose, cam_params, *, N=128, tn=2, tf=6, u=None, ray0=0, n_r
     elif device_rng:
         flags = _lib.FLAG_DEVICE_RNG
     else:
-        jit = torch.rand(n, N).to(dev)
+        jit, pending_rng = reference_rand(n, N, dev)
+        pending_rng.finish()
     lib = _lib.lib()
     h_pose = np.zeros((3, 4), dtype=np.float32)
     h_pose[:] = np.asarray(pose, dtype=np.float32)[:3, :4]
@@ -331,7 +353,8 @@ def sample_pdf(ts, w, Nf, *, u=None, device_rng=False, seed=0, ray_id0=0):
     elif device_rng:
         flags = _lib.FLAG_DEVICE_RNG
     else:
-        jit = torch.rand(B, Nf).to(dev)
+        jit, pending_rng = reference_rand(B, Nf, dev)
+        pending_rng.finish()
     out = torch.empty((B, Nc + Nf), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(_lib.lib().nerf_amd_sample_pdf(
@@ -352,7 +375,8 @@ def render_hierarchical(rays, net_coarse, net_fine, Nc=64, Nf=128, tn=2, tf=6, *
     _lib.require_cuda_f32(rays, "rays")
     dev, B = rays.device, rays.size(0)
     if u_c is None and not device_rng:
-        u_c = torch.rand(B, Nc).to(dev)
+        u_c, pending_rng = reference_rand(B, Nc, dev)
+        pending_rng.finish()
     if u_c is not None:
         tb = _tbins(tn, tf, Nc, dev)
         ts_c = (tb[1] - tb[0]) * u_c + tb[:-1]

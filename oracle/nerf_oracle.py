@@ -274,3 +274,45 @@ def adam_step(sd, grads, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, step=1, state=No
         new_sd[k] = p - lr * mhat / denom
         new_state[k] = (m, v)
     return new_sd, new_state
+
+
+# --------------------------------------------------------------------------
+# torch's CPU uniform stream (the jitter of reference utils/rendering.py:28-30), restated
+# --------------------------------------------------------------------------
+def mt19937_uniform(words, nxt, n):
+    """Continue at::mt19937 (ATen/core/MT19937RNGEngine.h) for n float32 uniforms
+    (ATen/core/DistributionsHelper.h: one 32-bit output per draw, u = (y & 0xFFFFFF) * 2^-24).
+    words: the 624 state words (uint32), nxt: first unread word of the current block (0..624).
+    Returns (u float32 [n], state words afterwards).  Pinned against torch.rand itself in
+    tests/test_oracle_golden.py; checker for csrc/host_rng.hip."""
+    import numpy as np
+    N_, M_ = 624, 397
+    D_ = N_ - M_
+    mt = np.asarray(words, dtype=np.uint32).copy()
+
+    def twist(u_, v_):
+        y = (u_ & np.uint32(0x80000000)) | (v_ & np.uint32(0x7fffffff))
+        return (y >> np.uint32(1)) ^ np.where(v_ & np.uint32(1), np.uint32(0x9908b0df), np.uint32(0)).astype(np.uint32)
+
+    def temper(y):
+        y = y ^ (y >> np.uint32(11))
+        y = y ^ ((y << np.uint32(7)) & np.uint32(0x9d2c5680))
+        y = y ^ ((y << np.uint32(15)) & np.uint32(0xefc60000))
+        return y ^ (y >> np.uint32(18))
+
+    out = np.empty(n, dtype=np.float32)
+    k = 0
+    while k < n:
+        if nxt >= N_:
+            new = mt.copy()
+            new[:D_] = mt[M_:] ^ twist(mt[:D_], mt[1:D_ + 1])
+            for lo in range(D_, N_ - 1, D_):
+                hi = min(lo + D_, N_ - 1)
+                new[lo:hi] = new[lo - D_:hi - D_] ^ twist(mt[lo:hi], mt[lo + 1:hi + 1])
+            new[N_ - 1] = new[M_ - 1] ^ twist(mt[N_ - 1:N_], new[0:1])[0]
+            mt, nxt = new, 0
+        take = min(N_ - nxt, n - k)
+        out[k:k + take] = (temper(mt[nxt:nxt + take]) & np.uint32(0xffffff)).astype(np.float32) * np.float32(2.0 ** -24)
+        k += take
+        nxt += take
+    return out, mt

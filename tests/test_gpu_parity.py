@@ -497,3 +497,89 @@ def test_render_image_dropin(dev, golden, synthetic, oracle):
     assert not rgb.is_cuda and float(gt.min()) == 1.0
     assert scaled_err(rgb.reshape(-1, 3).numpy(), g["rgb"]) <= F32_TOL
     assert scaled_err(disp.reshape(-1).numpy(), g["disp"]) <= F32_TOL
+
+
+def test_reference_rand_is_torch_rand(dev, oracle):
+    """A1: the reference's jitter `torch.rand(B, N)` on the CPU default generator
+    (utils/rendering.py:28-30) continued on the GPU (csrc/host_rng.hip): bit-identical values from
+    arbitrary positions of the stream, and the CPU generator afterwards continues exactly as if
+    torch had made the draw (so a program mixing both sees one stream)."""
+    from nerf_simple_amd.utils.host_rng import reference_rand, layout_ok
+    assert layout_ok()
+    saved = torch.get_rng_state()
+    try:
+        for seed, pre, shape in ((0, 0, (3, 5)), (1, 3, (7, 100)), (2, 623, (1, 5)), (3, 624, (13, 100)), (4, 100, (1, 624)),
+                                 (5, 0, (1000, 128)), (6, 77, (4096, 64)), (7, 500, (300, 2080))):
+            torch.manual_seed(seed)
+            if pre:
+                torch.rand(pre)
+            st = torch.get_rng_state()
+            want = torch.rand(*shape)
+            want_next = torch.rand(33)
+            torch.set_rng_state(st)
+            got, pending = reference_rand(shape[0], shape[1], dev)
+            pending.finish()
+            got_next = torch.rand(33)
+            assert torch.equal(got.cpu(), want), (seed, pre, shape)
+            assert torch.equal(got_next, want_next), (seed, pre, shape)
+    finally:
+        torch.set_rng_state(saved)
+
+
+def test_render_nerf_default_jitter_consumes_cpu_generator_like_the_reference(dev, synthetic):
+    """render_nerf without u / ts: one draw of B*N numbers from torch's CPU default generator per
+    call, as the reference -- the render equals the one with that explicit u, and the generator
+    ends where torch.rand(B, N) would have left it."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import render_nerf
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    net = Nerf().to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "structured"))
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
+    rays = camera_rays([pose], [12, 12, synthetic.focal_from_fov(12)]).to(dev)
+    B, N = rays.shape[0], 96
+    saved = torch.get_rng_state()
+    try:
+        torch.manual_seed(99)
+        torch.rand(7)
+        st = torch.get_rng_state()
+        u = torch.rand(B, N)
+        after = torch.rand(5)
+        with torch.no_grad():
+            want = render_nerf(rays, net, N, u=u.to(dev))
+            torch.set_rng_state(st)
+            got = render_nerf(rays, net, N)
+        assert torch.equal(torch.rand(5), after)
+        for a, b in zip(got, want):
+            assert torch.equal(a, b)
+    finally:
+        torch.set_rng_state(saved)
+
+
+def test_image_driver_default_jitter_is_the_reference_stream(dev, synthetic):
+    """The image drivers' batches draw their jitter ahead on a side stream (host_rng.ReferenceJitter):
+    the image equals the one rendered with the reference's own per-batch torch.rand pieces (ragged
+    last batch), and the CPU generator ends where those draws would have left it."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import _render_batched
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    net = Nerf().to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "structured"))
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
+    rays = camera_rays([pose], [30, 30, synthetic.focal_from_fov(30)]).to(dev).contiguous()
+    n, N, bs = rays.shape[0], 64, 256                      # 900 rays: batches 256, 256, 256, 132
+    saved = torch.get_rng_state()
+    try:
+        torch.manual_seed(31)
+        torch.rand(11)
+        st = torch.get_rng_state()
+        pieces = [torch.rand(min(s + bs, n) - s, N) for s in range(0, n, bs)]     # what the reference draws
+        after = torch.rand(6)
+        want = _render_batched(rays, net, bs, N, 2, 6, torch.cat(pieces).to(dev), False)
+        torch.set_rng_state(st)
+        got = _render_batched(rays, net, bs, N, 2, 6, None, False)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.rand(6), after)
+        assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+    finally:
+        torch.set_rng_state(saved)

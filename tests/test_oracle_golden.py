@@ -141,3 +141,35 @@ def test_psnr_formula(oracle):
     pred = gt + 0.01
     want = 20 * np.log10(0.5) - 10 * np.log10(1e-4)
     assert abs(float(oracle.img_psnr(gt, pred)) - want) < 1e-3
+
+
+def test_mt19937_restatement_matches_torch_rand(oracle):
+    """The oracle's restatement of torch's CPU uniform stream (the reference's jitter,
+    utils/rendering.py:28-30) against torch.rand itself, and the generator bookkeeping of
+    utils/host_rng.py: values bit-exact from arbitrary stream positions (fresh seed, mid-block,
+    block boundary, several blocks), and a generator patched with the predicted counters and
+    state words continues exactly like one that made the draws itself."""
+    import torch
+    from nerf_simple_amd.utils import host_rng as H
+    assert H.layout_ok()
+    saved = torch.get_rng_state()
+    try:
+        for seed, pre, n in ((0, 0, 10), (5, 3, 700), (7, 623, 5), (9, 624, 1300), (11, 100, 2000), (13, 0, 624),
+                             (14, 1, 623), (15, 17, 40000)):
+            torch.manual_seed(seed)
+            if pre:
+                torch.rand(pre)
+            st = torch.get_rng_state()
+            left, seeded, nxt, words = H._parse(st)
+            assert seeded == 1 and (left == 1 or nxt == 625 - left)
+            u, mt = oracle.mt19937_uniform(words.astype(np.uint32), 625 - left, n)
+            new_left, new_next, blocks = H._advance(left, nxt, n)
+            torch.set_rng_state(H._patched(st, new_left, new_next, mt if blocks else None))
+            mine_next = torch.rand(50).numpy()
+            torch.set_rng_state(st)
+            want = torch.rand(n).numpy()
+            ref_next = torch.rand(50).numpy()
+            assert np.array_equal(u, want), (seed, pre, n)
+            assert np.array_equal(mine_next, ref_next), (seed, pre, n)
+    finally:
+        torch.set_rng_state(saved)

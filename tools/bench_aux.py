@@ -62,7 +62,7 @@ with torch.no_grad():
         s = 800 * 800 * (64 + 192)
         print(json.dumps({"config": "4: 800x800 hierarchical 64 + (64+128) bf16, 1 GPU", "ms": dt * 1e3,
                           "mlp_evals_per_s": s / dt, "tflops": s * FLOP / dt / 1e12}))
-if "pcie" in which:        # reference-compatible jitter: one CPU torch.rand(B,N) per call + H2D copy
+if "pcie" in which:        # reference-compatible jitter: the torch.rand(B,N) stream of the CPU generator (host_rng.py)
     from nerf_simple_amd.utils.rendering import render_nerf
     with torch.no_grad():
         net = net_of("bf16")
@@ -70,8 +70,17 @@ if "pcie" in which:        # reference-compatible jitter: one CPU torch.rand(B,N
         for B in (16000, 640000):
             r = rays[:B].contiguous()
             dt = timed(lambda: render_nerf(r, net, 128, outputs=("rgb", "disp", "acc")), warm=1, reps=3)
-            print(json.dumps({"config": f"3 (parity mode): render_nerf B={B} N=128, jitter drawn on the CPU + PCIe copy",
+            print(json.dumps({"config": f"3 (parity mode): render_nerf B={B} N=128, torch CPU-generator jitter stream continued on the device",
                               "ms": dt * 1e3, "ray_samples_per_s": B * 128 / dt}))
+if "pcie" in which:        # the same mode through the image driver: batches of 64,000 rays, jitter drawn ahead
+    from nerf_simple_amd.utils.rendering import _render_batched
+    with torch.no_grad():
+        net = net_of("bf16")
+        rays = generate_rays(pose, [800, 800, synthetic.focal_from_fov(800)], dev)
+        for bs in (64000, 640000):
+            dt = timed(lambda: _render_batched(rays, net, bs, 128, 2, 6, None, False), warm=1, reps=3)
+            print(json.dumps({"config": f"3 (parity mode): 800x800x128 image driver, batch_size {bs}, reference jitter drawn "
+                              "on the device ahead of the batches", "ms": dt * 1e3, "ray_samples_per_s": 640000 * 128 / dt}))
 if "c5g" in which or "c5" in which:   # config 5 through the captured hipGraphs (training.GraphedTrainStep)
     from nerf_simple_amd.optim import FusedAdam
     from nerf_simple_amd.training import GraphedTrainStep
