@@ -83,6 +83,20 @@ def layout_ok():
     return _layout_ok
 
 
+_side_streams = {}
+
+
+def _side_stream(device):
+    """One high-priority side stream per device, reused: a fresh torch.cuda.Stream() comes from a
+    round-robin pool and now and then shares the default stream's hardware queue, which
+    serialises the generator behind the renders (seen in a kernel trace: same queue id, no
+    overlap); the high-priority pool maps to other queues."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device, priority=-1)
+    return _side_streams[key]
+
+
 class _Pending:
     """The state words coming back from the device; ``finish`` writes them into the generator."""
 
@@ -93,7 +107,7 @@ class _Pending:
         if self.state_out is None:
             return
         dev = self.state_out.device
-        side = torch.cuda.Stream(dev)
+        side = _side_stream(dev)
         with torch.cuda.stream(side):          # wait for the generator kernel only, not for the render behind it
             side.wait_event(self.event)
             host = self.state_out.to("cpu")
@@ -155,7 +169,7 @@ class ReferenceJitter:
         self.u = torch.empty((total, self.N), dtype=torch.float32, device=device)
         bufs = [torch.from_numpy(words.astype(np.uint32).view(np.int32)).to(device),
                 torch.empty(_N, dtype=torch.int32, device=device)]
-        self.side = torch.cuda.Stream(device)
+        self.side = _side_stream(device)
         self.side.wait_stream(cur_stream)                  # the buffers above were made on the current stream
         self.events, self.offsets = [], []
         any_blocks, row = False, 0
