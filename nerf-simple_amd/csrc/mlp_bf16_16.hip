@@ -49,6 +49,9 @@ namespace {
 
 // NCB 16-point column blocks per wave: 2 (8 waves, 2 per SIMD, <= 256 registers each; default) or
 // 4 (4 waves, 1 per SIMD, accumulators in AGPRs: every weight fragment read from LDS feeds 4 MFMAs)
+#ifndef NERF_AHEAD
+#define NERF_AHEAD 4
+#endif
 #ifndef NERF_NCB
 #define NERF_NCB 2
 #endif
@@ -229,7 +232,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
     constexpr int NT = chunk_tiles(CC);
     constexpr int RT0 = C * TPC;
     constexpr int F = NT * KS;                      // weight fragments (each feeds 2 MFMAs)
-    constexpr int AHEAD = 4;
+    constexpr int AHEAD = NERF_AHEAD;                // weight fragments in flight ahead of their MFMAs
     constexpr int BIAS_OFF = LDS_BIAS + (b16_bias_off(L) + 16 * RT0) * 4;
     constexpr int XBLK = D.extra_kind == 1 ? 2048 : 1024;
     // chunk-linear MFMA index m = (t*KS + ks)*2 + cb
