@@ -350,6 +350,23 @@ __device__ __forceinline__ float enc_lane(TwoF q, int idx) {
 template <bool RAYS>
 __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base, State& st) {
     const int col = c.lane & 15, g = c.lane >> 4;
+    // Counter-RNG jitter: the four lane groups of a point would each evaluate the same Philox
+    // (40 quarter-rate integer multiplies), once per column block.  Instead every lane evaluates
+    // it once, for point (lane & 31) of the wave's 32, and the lanes fetch their two points'
+    // draws with a wave shuffle: the same numbers for half the work.
+    float u_mine = 0.f;
+    bool dev_rng = false;
+    if constexpr (RAYS && NCB == 2) {
+        dev_rng = (a.flags & NERF_FLAG_DEVICE_RNG) && !(a.flags & NERF_FLAG_TS_GIVEN);
+#if defined(NERF_EXP) && NERF_EXP == 9
+        dev_rng = false;                 // A/B: every lane evaluates Philox for both of its points (the old form)
+#endif
+        if (dev_rng) {
+            long long pm = tile_base + c.wave * 32 + (c.lane & 31);
+            if (pm >= a.P) pm = a.P - 1;
+            u_mine = device_rng_uniform(a, pm);
+        }
+    }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         long long p = tile_base + c.wave * (16 * NCB) + cb * 16 + col;
@@ -358,7 +375,8 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
         if (!valid) p = a.P - 1;
         PointIn pt;
         if constexpr (RAYS) {
-            pt = fetch_point_rays(a, p);
+            const float u_cb = (NCB == 2) ? __shfl(u_mine, cb * 16 + col) : 0.f;
+            pt = fetch_point_rays(a, p, u_cb, dev_rng);
             if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
         } else {
             pt = fetch_point_pts(a, p);

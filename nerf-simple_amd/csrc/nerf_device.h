@@ -107,7 +107,15 @@ struct PointIn {
 // rounded separately (__fmul_rn/__fadd_rn: no fma contraction) exactly like
 // the reference's separate torch ops, so ts and locs are bit-identical to the
 // CPU path given the same u.
-__device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long p) {
+// the counter RNG's draw for global point p of this launch (FLAG_DEVICE_RNG)
+__device__ __forceinline__ float device_rng_uniform(const MlpArgs& a, long long p) {
+    const long long b = p / a.N;
+    const int i = (int)(p - b * a.N);
+    return philox_uniform(a.seed, (unsigned long long)((a.ray_id0 + b) * a.N + i));
+}
+
+// u_pre: the point's device-RNG draw when the caller already has it (have_u), see mlp_bf16_16.hip stage_inputs
+__device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long p, float u_pre = 0.f, bool have_u = false) {
     PointIn r;
     const long long b = p / a.N;
     const int i = (int)(p - b * a.N);
@@ -120,7 +128,7 @@ __device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long 
     } else {
         float u;
         if (a.flags & NERF_FLAG_DEVICE_RNG)
-            u = philox_uniform(a.seed, (unsigned long long)((a.ray_id0 + b) * a.N + i));
+            u = have_u ? u_pre : philox_uniform(a.seed, (unsigned long long)((a.ray_id0 + b) * a.N + i));
         else
             u = a.u[p];
         const float bin_diff = __fsub_rn(a.tbins[1], a.tbins[0]);
