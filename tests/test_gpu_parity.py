@@ -425,7 +425,7 @@ def test_sample_pdf_vs_oracle(dev, oracle):
     oracle's restatement of the NeRF paper's sample_pdf."""
     from nerf_simple_amd.utils.rendering import sample_pdf
     gen = torch.Generator().manual_seed(31)
-    for B, Nc, Nf in ((64, 64, 128), (7, 32, 64), (5, 128, 100), (3, 256, 256)):
+    for B, Nc, Nf in ((64, 64, 128), (7, 32, 64), (5, 128, 100), (3, 256, 256), (3, 64, 400), (2, 3, 1)):
         u_c = torch.rand(B, Nc, generator=gen)
         ts = oracle.sample_ts(u_c)
         w = torch.rand(B, Nc, generator=gen) ** 4           # peaky weights
