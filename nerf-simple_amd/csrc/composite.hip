@@ -10,8 +10,9 @@
 // DISPARITY 1/max(1e-10, depth/acc) with torch.max's NaN propagation (acc == 0
 // gives NaN exactly like the reference).
 //
-// HBM-bound: 20 B read per sample (+8 B written when alpha / w are requested)
-// and 20 B written per ray.
+// 20 B read per sample (+8 B written when alpha / w are requested) and 20 B written per ray.
+// Not HBM-bound in practice: the exact-fp32 softplus / exp (ocml expf, log1pf) and the two scans
+// cost ~400 VALU instructions per 64 samples, which is what sets its 3.4 TB/s.
 #include "nerf_device.h"
 
 namespace {
