@@ -248,8 +248,8 @@ class GraphedTrainStep:
     At 4096 rays x 64 samples the eager step spends a tenth of its time between 14 small
     launches; the graph removes those gaps and the per-step Python / autograd bookkeeping.
     Step-dependent scalars do not live in kernel arguments: the jitter comes from the ``u``
-    buffer (filled per call; default one ``torch.rand(B, N)`` on the CPU generator, the
-    reference's RNG consumption), Adam's learning rate and bias corrections from a 6-float
+    buffer (filled per call; default the reference's one ``torch.rand(B, N)`` draw from the CPU
+    generator, continued on the device by utils/host_rng.py), Adam's learning rate and bias corrections from a 6-float
     device vector (nerf_amd_adam_step_hyper).  ``optimizer`` must be ``optim.FusedAdam``.
 
     ``step(rays, gt, u=None, decay=1.0)`` returns the loss as a 0-d device tensor (no sync).
@@ -377,7 +377,10 @@ class GraphedTrainStep:
         self.rays.copy_(rays, non_blocking=True)
         self.gt.copy_(gt, non_blocking=True)
         if u is None:
-            u = torch.rand(self.B, self.N)                      # the reference's one CPU draw per call
+            # the reference's one draw per call from torch's CPU generator, continued on the device
+            from .utils.host_rng import reference_rand
+            u, pending = reference_rand(self.B, self.N, self.dev)
+            pending.finish()
         self.u.copy_(u, non_blocking=True)
         self.opt.step_count += 1
         self._set_hyper(self.opt.step_count)
