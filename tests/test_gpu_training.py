@@ -355,6 +355,22 @@ def test_graphed_train_step_matches_eager(dev, golden, synthetic):
             stepper = GraphedTrainStep(net, opt, rays.shape[0], N)
             losses = [float(stepper.step(rays, gt, u=us[i], decay=decay)) for i in range(6)]
             assert opt.step_count == 6
+            # without u the step draws torch.rand(B, N) from the CPU generator like the reference
+            saved = torch.get_rng_state()
+            try:
+                torch.manual_seed(77)
+                st = torch.get_rng_state()
+                want_u = torch.rand(rays.shape[0], N)
+                want_next = torch.rand(3)
+                torch.set_rng_state(st)
+                probe_net_state = opt.flat.clone()
+                stepper.step(rays, gt)
+                assert torch.equal(stepper.u.cpu(), want_u) and torch.equal(torch.rand(3), want_next)
+                opt.flat.copy_(probe_net_state)          # undo that extra update for the comparison below
+                net.repack_from_flat(opt.flat)
+                opt.step_count -= 1
+            finally:
+                torch.set_rng_state(saved)
         else:
             losses = [float(train_step(net, opt, rays, gt, N, u=us[i], decay=decay)) for i in range(6)]
         assert abs(opt.param_groups[0]["lr"] - 5e-4 * decay ** 6) < 1e-12
