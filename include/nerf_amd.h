@@ -227,6 +227,18 @@ int nerf_amd_adam_step(float* params, const float* grads, float* exp_avg, float*
 int nerf_amd_mt19937_uniform(const uint32_t* state624, int next, float* out, int64_t n,
                              uint32_t* state_out624, void* stream);
 
+/* The same stream produced by several workgroups: after the generator's unread words the stream is
+ * cut into segments of seg_words words (a multiple of 624); segment b starts from the state
+ * advanced by b * seg_words words, obtained by MT19937 jump-ahead -- polys[m][624] holds
+ * x^(seg_words * 2^m) mod the characteristic polynomial (utils/mt19937_jump.npz, made and verified by
+ * tools/make_mt_jump.py), m < levels, and the start states follow from the first by a doubling
+ * tree of GF(2) convolutions.  seg_states: workspace of nerf_amd_mt19937_segments(next, n,
+ * seg_words) * 624 words.  Values and final state identical to nerf_amd_mt19937_uniform. */
+int64_t nerf_amd_mt19937_segments(int next, int64_t n, int64_t seg_words);
+int nerf_amd_mt19937_uniform_par(const uint32_t* state624, int next, float* out, int64_t n,
+                                 uint32_t* state_out624, const uint32_t* polys, int levels,
+                                 int64_t seg_words, uint32_t* seg_states, void* stream);
+
 /* The same update with the step-dependent scalars in DEVICE memory: hyper[6] = {lr, beta1,
  * beta2, eps, 1 - beta1^step, sqrt(1 - beta2^step)} (fp32).  The launch carries no per-step
  * argument, so it can sit inside a captured hipGraph replayed every iteration while the host

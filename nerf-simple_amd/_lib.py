@@ -60,6 +60,8 @@ _SIGNATURES = {
     "nerf_amd_adam_step": (_i32, [_vp, _vp, _vp, _vp, _i64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                   ctypes.c_float, _i64, _vp]),
     "nerf_amd_mt19937_uniform": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
+    "nerf_amd_mt19937_segments": (_i64, [_i32, _i64, _i64]),
+    "nerf_amd_mt19937_uniform_par": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _i64, _vp, _vp]),
     "nerf_amd_adam_step_hyper": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "nerf_amd_render_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _u32, _u64, _i64,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),

@@ -31,6 +31,8 @@ int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, long long, hipStream_t);
 int nerf_amd_launch_mt19937_uniform(const uint32_t*, int, float*, long long, uint32_t*, hipStream_t);
+int nerf_amd_launch_mt19937_uniform_par(const uint32_t*, int, float*, long long, uint32_t*, const uint32_t*, int, long long,
+                                        uint32_t*, hipStream_t);
 int nerf_amd_launch_adam_hyper(float*, const float*, float*, float*, long long, const float*, hipStream_t);
 int nerf_amd_launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float, float,
                          hipStream_t);
@@ -362,6 +364,25 @@ int nerf_amd_mt19937_uniform(const uint32_t* state624, int next, float* out, int
     if (n < 0 || next < 0 || next > 624) return NERF_AMD_EINVAL;
     if (!state624 || !state_out624 || (n > 0 && !out)) return NERF_AMD_EINVAL;
     return nerf_amd_launch_mt19937_uniform(state624, next, out, n, state_out624, S(stream));
+}
+
+int64_t nerf_amd_mt19937_segments(int next, int64_t n, int64_t seg_words) {
+    if (n < 0 || next < 0 || next > 624 || seg_words <= 0 || seg_words % 624) return NERF_AMD_EINVAL;
+    const int64_t avail = 624 - next;
+    return n > avail + seg_words ? 1 + (n - avail - seg_words + seg_words - 1) / seg_words : 1;
+}
+
+int nerf_amd_mt19937_uniform_par(const uint32_t* state624, int next, float* out, int64_t n, uint32_t* state_out624,
+                                 const uint32_t* polys, int levels, int64_t seg_words, uint32_t* seg_states,
+                                 void* stream) {
+    if (n < 0 || next < 0 || next > 624 || levels < 0 || levels > 30) return NERF_AMD_EINVAL;
+    if (seg_words <= 0 || seg_words % 624) return NERF_AMD_EINVAL;
+    if (!state624 || !state_out624 || (n > 0 && !out)) return NERF_AMD_EINVAL;
+    const int64_t nseg = nerf_amd_mt19937_segments(next, n, seg_words);
+    if (nseg > 1 && (!polys || !seg_states)) return NERF_AMD_EINVAL;
+    if (nseg > ((int64_t)1 << levels)) return NERF_AMD_EUNSUP;
+    return nerf_amd_launch_mt19937_uniform_par(state624, next, out, n, state_out624, polys, levels, seg_words, seg_states,
+                                               S(stream));
 }
 
 int nerf_amd_adam_step_hyper(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

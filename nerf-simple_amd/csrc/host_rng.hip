@@ -38,11 +38,29 @@ __device__ __forceinline__ float mt_uniform(unsigned y) {
     return (float)(y & 0xffffffu) * 5.9604644775390625e-08f;   // 2^-24, exact
 }
 
-__global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __restrict__ state_in, int next0,
-                                                              float* __restrict__ out, long long n,
-                                                              unsigned* __restrict__ state_out) {
+// Segment b of the stream (blockIdx.x): b = 0 starts from the generator's state (unread words from
+// next0, then seg_words draws of new blocks); b >= 1 starts from seg_states[b] = that state advanced by
+// b * seg_words words (mt19937_jump_kernel), all of it unread-exhausted, and produces seg_words draws.
+// The last segment also hands back the state words.  A single segment (gridDim.x == 1) is the whole call.
+__global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __restrict__ state_in0, int next00,
+                                                              float* __restrict__ out0, long long n_total,
+                                                              unsigned* __restrict__ state_out,
+                                                              const unsigned* __restrict__ seg_states,
+                                                              long long seg_words) {
     __shared__ unsigned buf[2][MT_N];
     const int t = threadIdx.x;
+    const int seg = blockIdx.x;
+    const bool last_seg = seg == (int)gridDim.x - 1;
+    const long long avail0 = MT_N - next00;                         // unread words of the generator's block
+    const unsigned* state_in = seg == 0 ? state_in0 : seg_states + (long long)seg * MT_N;
+    const int next0 = seg == 0 ? next00 : MT_N;
+    const long long off = seg == 0 ? 0 : avail0 + (long long)seg * seg_words;
+    float* out = out0 + off;
+    long long n = n_total - off;
+    if (gridDim.x > 1) {
+        const long long cap = seg == 0 ? avail0 + seg_words : seg_words;
+        if (n > cap) n = cap;
+    }
     const bool producer = t < 256;
     const bool own = t < MT_D;                         // producer that owns words t, t+227 and (t < 169) t+454
     const bool own3 = t + 2 * MT_D < MT_N - 1;
@@ -99,6 +117,7 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __
         cur ^= 1;
         last = buf[cur][MT_M - 1] ^ mt_twist(last, buf[cur][0]);
     }
+    if (!last_seg) return;
     // the state words afterwards: the producers' registers when blocks were formed, else the input
     if (own) {
         state_out[t] = r0;
@@ -108,11 +127,97 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __
     if (t == 255) state_out[MT_N - 1] = last;
 }
 
+// ---- jump-ahead -------------------------------------------------------------------------------
+// states[dst0 + j] = F^J states[src0 + j], j = blockIdx.x, F = MT19937's one-word step, J given by
+// poly = x^J mod phi(x) (tools/make_mt_jump.py; 19937 bits in 624 words).  With w_0, w_1, ... the raw
+// word sequence that starts with the source state's 624 words, F^i s is the window w_i .. w_{i+623},
+// so (F^J s)[k] = XOR over the set bits i of poly of w[i + k]: a GF(2) convolution.  The workgroup
+// first extends the sequence to 33 blocks in LDS (80 KiB; 32 block steps with the chain scheme of
+// the generator), then each thread accumulates its three output words -- the bit test is
+// wave-uniform, the LDS reads of consecutive threads consecutive.  The 31 low bits of word 0 of a
+// state are not part of it (a block-aligned state is only ever regenerated from): they come out
+// arbitrary and are never read.
+constexpr int MT_JUMP_BLOCKS = 33;                       // 33 * 624 = 20592 >= 19937 + 623 words
+constexpr int MT_DEG = 19937;
+
+__global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict__ states, const unsigned* __restrict__ poly,
+                                                           int src0, int dst0) {
+    extern __shared__ unsigned w[];                       // [MT_JUMP_BLOCKS * 624]
+    const int t = threadIdx.x;
+    const unsigned* src = states + (long long)(src0 + blockIdx.x) * MT_N;
+    for (int i = t; i < MT_N; i += 256) w[i] = src[i];
+    __syncthreads();
+    const bool own = t < MT_D, own3 = t + 2 * MT_D < MT_N - 1;
+    for (int b = 0; b < MT_JUMP_BLOCKS - 1; ++b) {
+        const unsigned* old = w + b * MT_N;
+        unsigned* nw = w + (b + 1) * MT_N;
+        if (own) {
+            const unsigned x = old[t + MT_M] ^ mt_twist(old[t], old[t + 1]);
+            const unsigned y = x ^ mt_twist(old[t + MT_D], old[t + MT_D + 1]);
+            nw[t] = x;
+            nw[t + MT_D] = y;
+            if (own3) nw[t + 2 * MT_D] = y ^ mt_twist(old[t + 2 * MT_D], old[t + 2 * MT_D + 1]);
+        }
+        __syncthreads();
+        if (t == 0) nw[MT_N - 1] = nw[MT_M - 1] ^ mt_twist(old[MT_N - 1], nw[0]);
+        __syncthreads();
+    }
+    unsigned a0 = 0, a1 = 0, a2 = 0;
+    const bool third = t + 512 < MT_N;
+    for (int iw = 0; iw < MT_N; ++iw) {
+        unsigned g = __builtin_amdgcn_readfirstlane(poly[iw]);            // wave-uniform: scalar bit tests
+        const int base = iw * 32;
+        while (g) {
+            const int bit = __builtin_ctz(g);
+            g &= g - 1;
+            const int i = base + bit;
+            if (i >= MT_DEG) break;
+            a0 ^= w[i + t];
+            a1 ^= w[i + t + 256];
+            if (third) a2 ^= w[i + t + 512];
+        }
+    }
+    unsigned* dst = states + (long long)(dst0 + blockIdx.x) * MT_N;
+    dst[t] = a0;
+    dst[t + 256] = a1;
+    if (third) dst[t + 512] = a2;
+}
+
 }  // namespace
+
+// Parallel form: the stream is cut into segments of seg_words words (a multiple of 624) after the
+// generator's unread words; polys[m] = x^(seg_words * 2^m) mod phi; seg_states: workspace [S][624].
+extern "C" int nerf_amd_launch_mt19937_uniform_par(const uint32_t* state_in, int next, float* out, long long n,
+                                                   uint32_t* state_out, const uint32_t* polys, int levels,
+                                                   long long seg_words, uint32_t* seg_states, hipStream_t stream) {
+    (void)hipGetLastError();
+    const long long avail = MT_N - next;
+    long long S = 1;
+    if (n > avail + seg_words) S = 1 + (n - avail - seg_words + seg_words - 1) / seg_words;
+    if (S > (1ll << levels)) return -2;
+    if (S > 1) {
+        hipError_t e = hipMemcpyAsync(seg_states, state_in, MT_N * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return (int)e;
+        const int lds = MT_JUMP_BLOCKS * MT_N * (int)sizeof(unsigned);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt19937_jump_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return (int)e;
+        for (int m = 0; (1ll << m) < S; ++m) {                      // doubling tree over the segment start states
+            const long long have = 1ll << m;
+            const long long count = S - have < have ? S - have : have;
+            hipLaunchKernelGGL(mt19937_jump_kernel, dim3((unsigned)count), dim3(256), lds, stream, seg_states,
+                               polys + (long long)m * MT_N, 0, (int)have);
+        }
+    }
+    hipLaunchKernelGGL(mt19937_uniform_kernel, dim3((unsigned)S), dim3(512), 0, stream, state_in, next, out, n, state_out,
+                       seg_states, seg_words);
+    return (int)hipGetLastError();
+}
 
 extern "C" int nerf_amd_launch_mt19937_uniform(const uint32_t* state_in, int next, float* out, long long n,
                                                uint32_t* state_out, hipStream_t stream) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(mt19937_uniform_kernel, dim3(1), dim3(512), 0, stream, state_in, next, out, n, state_out);
+    hipLaunchKernelGGL(mt19937_uniform_kernel, dim3(1), dim3(512), 0, stream, state_in, next, out, n, state_out,
+                       (const unsigned*)nullptr, 0ll);
     return (int)hipGetLastError();
 }

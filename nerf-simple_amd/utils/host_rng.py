@@ -83,6 +83,42 @@ def layout_ok():
     return _layout_ok
 
 
+_jump = {}
+
+
+def _jump_polys(device):
+    """(polys [levels, 624] on ``device``, levels, seg_words) from utils/mt19937_jump.npz, or None."""
+    key = str(device)
+    if key not in _jump:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mt19937_jump.npz")
+        try:
+            z = np.load(path)
+            polys = torch.from_numpy(z["polys"].astype(np.uint32).view(np.int32)).to(device)
+            _jump[key] = (polys, int(polys.shape[0]), int(z["seg_words"]))
+        except Exception:
+            _jump[key] = None
+    return _jump[key]
+
+
+def _launch_uniform(words_dev, next0, out, n, state_out, device):
+    """nerf_amd_mt19937_uniform, or its multi-workgroup form when the draw spans several segments."""
+    lib = _lib.lib()
+    st = _lib.stream_ptr(device)
+    jp = _jump_polys(device)
+    if jp is not None:
+        polys, levels, seg_words = jp
+        S = int(lib.nerf_amd_mt19937_segments(int(next0), int(n), seg_words))
+        if 1 < S <= (1 << levels):
+            ws = torch.empty((S, _N), dtype=torch.int32, device=device)
+            _lib.check(lib.nerf_amd_mt19937_uniform_par(_lib.ptr(words_dev), int(next0), _lib.ptr(out), int(n),
+                                                        _lib.ptr(state_out), _lib.ptr(polys), levels, seg_words,
+                                                        _lib.ptr(ws), st), "nerf_amd_mt19937_uniform_par")
+            ws.record_stream(torch.cuda.current_stream(device))
+            return
+    _lib.check(lib.nerf_amd_mt19937_uniform(_lib.ptr(words_dev), int(next0), _lib.ptr(out), int(n), _lib.ptr(state_out), st),
+               "nerf_amd_mt19937_uniform")
+
+
 _side_streams = {}
 
 
@@ -134,9 +170,7 @@ def reference_rand(B, N, device):
     state_out = torch.empty(_N, dtype=torch.int32, device=device)
     with torch.cuda.device(device):
         # first unread word of the current block: 625 - left (624 = block exhausted, as after seeding)
-        _lib.check(lib.nerf_amd_mt19937_uniform(_lib.ptr(words_dev), _N + 1 - int(left), _lib.ptr(u), n,
-                                                _lib.ptr(state_out), _lib.stream_ptr(device)),
-                   "nerf_amd_mt19937_uniform")
+        _launch_uniform(words_dev, _N + 1 - int(left), u, n, state_out, device)
         if blocks == 0:                         # the state words did not change: counters only, no read-back
             torch.set_rng_state(_patched(state, new_left, new_next, None))
             return u, _Pending(None, 0, 0, None, None)
@@ -146,13 +180,13 @@ def reference_rand(B, N, device):
 
 
 class ReferenceJitter:
-    """The jitter of CONSECUTIVE render_nerf calls -- the batches of an image driver -- drawn
-    ahead of the renders: the reference draws ``torch.rand(B_k, N)`` inside each call, i.e.
-    consecutive pieces of one stream, so all pieces can be enqueued at once on a side stream
-    (each launch continues from the previous one's state words, device to device) and batch k+1
-    is generated while batch k renders.  ``batch(k)`` makes the current stream wait for piece k
-    and returns it; ``finish()`` restores torch's CPU generator to where the reference's draws
-    would have left it."""
+    """The jitter of CONSECUTIVE render_nerf calls -- the batches of an image driver.  The
+    reference draws ``torch.rand(B_k, N)`` inside each call, i.e. consecutive pieces of one stream,
+    so the whole image's draws are produced by ONE launch sequence before the first batch (with
+    jump-ahead that is ~3 ms for 8.2e7 draws, far cheaper than overlapping per-batch pieces with the
+    renders: the jump kernels need 80 KiB of LDS and would wait for the persistent render grid).
+    ``batch(k)`` returns piece k; ``finish()`` restores torch's CPU generator to where the
+    reference's draws would have left it."""
 
     def __init__(self, batch_rays, N, device):
         self.device, self.N = device, int(N)
@@ -161,45 +195,15 @@ class ReferenceJitter:
         self.pending = _Pending(None, 0, 0, None, None)
         if self.fallback:
             return
-        lib = _lib.lib()
-        state = torch.get_rng_state()
-        left, _seeded, nxt, words = _parse(state)
-        total = sum(self.sizes)
-        cur_stream = torch.cuda.current_stream(device)
-        self.u = torch.empty((total, self.N), dtype=torch.float32, device=device)
-        bufs = [torch.from_numpy(words.astype(np.uint32).view(np.int32)).to(device),
-                torch.empty(_N, dtype=torch.int32, device=device)]
-        self.side = _side_stream(device)
-        self.side.wait_stream(cur_stream)                  # the buffers above were made on the current stream
-        self.events, self.offsets = [], []
-        any_blocks, row = False, 0
-        with torch.cuda.device(device), torch.cuda.stream(self.side):
-            for b in self.sizes:
-                n = b * self.N
-                piece = self.u[row:row + b]
-                _lib.check(lib.nerf_amd_mt19937_uniform(_lib.ptr(bufs[0]), _N + 1 - int(left), _lib.ptr(piece), n,
-                                                        _lib.ptr(bufs[1]), _lib.stream_ptr(device)),
-                           "nerf_amd_mt19937_uniform")
-                left, nxt, blocks = _advance(left, nxt, n)
-                any_blocks = any_blocks or blocks > 0
-                bufs.reverse()                              # this launch's output state is the next one's input
-                ev = torch.cuda.Event()
-                ev.record(self.side)
-                self.events.append(ev)
-                self.offsets.append(row)
-                row += b
-        self.u.record_stream(self.side)
-        for t_ in bufs:
-            t_.record_stream(self.side)
-        if any_blocks:
-            self.pending = _Pending(state, left, nxt, bufs[0], self.events[-1])
-        else:
-            torch.set_rng_state(_patched(state, left, nxt, None))
+        self.offsets, row = [], 0
+        for b in self.sizes:
+            self.offsets.append(row)
+            row += b
+        self.u, self.pending = reference_rand(row, self.N, device)
 
     def batch(self, k):
         if self.fallback:
             return torch.rand(self.sizes[k], self.N).to(self.device)
-        torch.cuda.current_stream(self.device).wait_event(self.events[k])
         return self.u[self.offsets[k]:self.offsets[k] + self.sizes[k]]
 
     def finish(self):

@@ -4,6 +4,7 @@ tests/golden/make_golden.py captured from the reference source itself.
 Same torch build + CPU on both sides, so the restatement is required to be
 BIT-IDENTICAL wherever it issues the same ops (everything except Adam, whose
 fused torch implementation orders a few fp32 ops differently)."""
+import os
 import numpy as np
 import torch
 
@@ -173,3 +174,32 @@ def test_mt19937_restatement_matches_torch_rand(oracle):
             assert np.array_equal(mine_next, ref_next), (seed, pre, n)
     finally:
         torch.set_rng_state(saved)
+
+
+def test_mt19937_jump_polynomials():
+    """utils/mt19937_jump.npz (made by tools/make_mt_jump.py) against first principles: the
+    characteristic polynomial is recomputed by Berlekamp-Massey (degree 19937, the 135 terms of
+    the literature), the stored x^(seg_words 2^m) mod phi are recomputed for two levels, and a
+    jump evaluated as the GF(2) convolution over the raw word sequence equals plain sequential
+    generation (a shorter jump, so the CPU finishes in a second)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_mt_jump", os.path.join(root, "tools", "make_mt_jump.py"))
+    J = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(J)
+    z = np.load(os.path.join(root, "nerf-simple_amd", "utils", "mt19937_jump.npz"))
+    phi = J.char_poly()
+    assert phi.bit_length() - 1 == 19937 and phi.bit_count() == 135
+    stored_phi = int.from_bytes(z["phi"].astype("<u4").tobytes(), "little") | (int(z["phi_top"]) << (32 * 624))
+    assert stored_phi == phi
+    seg_words = int(z["seg_words"])
+    assert seg_words % 624 == 0 and z["polys"].shape == (8, 624)
+    for m in (0, 5):
+        assert np.array_equal(z["polys"][m], J.to_words(J.x_pow_mod(seg_words << m, phi)))
+    rng = np.random.default_rng(3)
+    s = rng.integers(0, 2 ** 32, size=624, dtype=np.uint64).astype(np.uint32)
+    blocks = 300
+    g = J.to_words(J.x_pow_mod(624 * blocks, phi))
+    want = J.raw_words(s, blocks)[blocks * 624:(blocks + 1) * 624]
+    got = J.apply_jump(s, g)
+    assert np.array_equal(got[1:], want[1:]) and ((int(got[0]) ^ int(want[0])) & 0x80000000) == 0

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel trace (rocprofv3) of the reference-jitter modes of tools/bench_aux.py pcie: prints start / duration / hardware
-# queue of the MT19937 generator pieces and the MLP renders, i.e. whether they overlap.  Run on the GPU box.
+# queue of the MT19937 generator kernels and the MLP renders.  Run on the GPU box.
 set -e
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/trace_pcie
