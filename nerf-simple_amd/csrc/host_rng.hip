@@ -18,7 +18,8 @@
 // which travel through a double-buffered LDS copy -- one barrier and one LDS round trip per
 // block.  Word 623 is formed by every thread from two broadcast reads and carried in a register.
 // Waves 4..7 are consumers: while the producers form block b+1 they read block b from LDS,
-// temper, convert and store it (coalesced).  One workgroup (the stream is one sequence).
+// temper, convert and store it (coalesced).  A workgroup produces one sequential piece of the
+// stream; long draws are cut into segments whose start states come from jump-ahead (below).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
