@@ -222,8 +222,8 @@ int nerf_amd_adam_step(float* params, const float* grads, float* exp_avg, float*
  * words (device memory); next: index of the first unread word of the current block, 0..624
  * (624 = the block is used up); out[n] receives the next n draws; state_out624 the state words
  * afterwards (equal to state624 if no new block was needed).  The host side keeps the
- * generator's counters (utils/rendering.py reference_rand).  One workgroup; ~1 barrier per 624
- * draws. */
+ * generator's counters (utils/host_rng.py reference_rand).  One workgroup; ~1 barrier per 624
+ * draws; see nerf_amd_mt19937_uniform_par for long draws. */
 int nerf_amd_mt19937_uniform(const uint32_t* state624, int next, float* out, int64_t n,
                              uint32_t* state_out624, void* stream);
 

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __
 // poly = x^J mod phi(x) (tools/make_mt_jump.py; 19937 bits in 624 words).  With w_0, w_1, ... the raw
 // word sequence that starts with the source state's 624 words, F^i s is the window w_i .. w_{i+623},
 // so (F^J s)[k] = XOR over the set bits i of poly of w[i + k]: a GF(2) convolution.  The workgroup
-// first extends the sequence to 33 blocks in LDS (80 KiB; 32 block steps with the chain scheme of
+// first extends the sequence to 33 blocks in LDS (83 KiB with the polynomial; 32 block steps with the chain scheme of
 // the generator), then each thread accumulates its three output words -- the bit test is
 // wave-uniform, the LDS reads of consecutive threads consecutive.  The 31 low bits of word 0 of a
 // state are not part of it (a block-aligned state is only ever regenerated from): they come out
@@ -141,12 +141,21 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __
 constexpr int MT_JUMP_BLOCKS = 33;                       // 33 * 624 = 20592 >= 19937 + 623 words
 constexpr int MT_DEG = 19937;
 
+constexpr int MT_JUMP_SPLIT = 8;                         // workgroups sharing one jump's convolution (624 = 8 * 78 words)
+
 __global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict__ states, const unsigned* __restrict__ poly,
                                                            int src0, int dst0) {
-    extern __shared__ unsigned w[];                       // [MT_JUMP_BLOCKS * 624]
+    // blockIdx.x = jump * MT_JUMP_SPLIT + part: the parts of a jump each rebuild the word sequence (cheap)
+    // and convolve a slice of the polynomial, combining into the zero-initialised destination with atomicXor
+    const int jump = blockIdx.x / MT_JUMP_SPLIT, part = blockIdx.x % MT_JUMP_SPLIT;
+    extern __shared__ unsigned w[];                       // [MT_JUMP_BLOCKS * 624] + the polynomial [624]
+    unsigned* gp = w + MT_JUMP_BLOCKS * MT_N;             // (624 dependent global loads cost 0.6 ms)
     const int t = threadIdx.x;
-    const unsigned* src = states + (long long)(src0 + blockIdx.x) * MT_N;
-    for (int i = t; i < MT_N; i += 256) w[i] = src[i];
+    const unsigned* src = states + (long long)(src0 + jump) * MT_N;
+    for (int i = t; i < MT_N; i += 256) {
+        w[i] = src[i];
+        gp[i] = poly[i];
+    }
     __syncthreads();
     const bool own = t < MT_D, own3 = t + 2 * MT_D < MT_N - 1;
     for (int b = 0; b < MT_JUMP_BLOCKS - 1; ++b) {
@@ -163,25 +172,31 @@ __global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict_
         if (t == 0) nw[MT_N - 1] = nw[MT_M - 1] ^ mt_twist(old[MT_N - 1], nw[0]);
         __syncthreads();
     }
+    // Branch-free: every bit position is visited and the loaded words are masked with the (scalar,
+    // wave-uniform) polynomial bit, so the LDS reads of 8 positions are in flight together.  A loop
+    // over the set bits only (half as many reads) exposed a full LDS round trip per bit: 0.83 ms.
     unsigned a0 = 0, a1 = 0, a2 = 0;
     const bool third = t + 512 < MT_N;
-    for (int iw = 0; iw < MT_N; ++iw) {
-        unsigned g = __builtin_amdgcn_readfirstlane(poly[iw]);            // wave-uniform: scalar bit tests
-        const int base = iw * 32;
-        while (g) {
-            const int bit = __builtin_ctz(g);
-            g &= g - 1;
-            const int i = base + bit;
-            if (i >= MT_DEG) break;
-            a0 ^= w[i + t];
-            a1 ^= w[i + t + 256];
-            if (third) a2 ^= w[i + t + 512];
+    const int t2 = third ? t + 512 : t;                   // threads without a third word re-read their first
+    constexpr int PER = MT_N / MT_JUMP_SPLIT;
+    static_assert(PER * MT_JUMP_SPLIT == MT_N, "polynomial words per part");
+    for (int iw = part * PER; iw < (part + 1) * PER; ++iw) {
+        const unsigned g = __builtin_amdgcn_readfirstlane(gp[iw]);
+        if (g == 0) continue;
+        const unsigned* wi = w + iw * 32 + t;
+#pragma unroll 8
+        for (int b = 0; b < 32; ++b) {
+            const unsigned m = 0u - ((g >> b) & 1u);
+            a0 ^= wi[b] & m;
+            a1 ^= wi[b + 256] & m;
+            a2 ^= wi[b + (t2 - t)] & m;
         }
     }
-    unsigned* dst = states + (long long)(dst0 + blockIdx.x) * MT_N;
-    dst[t] = a0;
-    dst[t + 256] = a1;
-    if (third) dst[t + 512] = a2;
+    if (!third) a2 = 0;
+    unsigned* dst = states + (long long)(dst0 + jump) * MT_N;
+    atomicXor(dst + t, a0);
+    atomicXor(dst + t + 256, a1);
+    if (third) atomicXor(dst + t + 512, a2);
 }
 
 }  // namespace
@@ -197,16 +212,18 @@ extern "C" int nerf_amd_launch_mt19937_uniform_par(const uint32_t* state_in, int
     if (n > avail + seg_words) S = 1 + (n - avail - seg_words + seg_words - 1) / seg_words;
     if (S > (1ll << levels)) return -2;
     if (S > 1) {
-        hipError_t e = hipMemcpyAsync(seg_states, state_in, MT_N * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        hipError_t e = hipMemsetAsync(seg_states, 0, (size_t)S * MT_N * sizeof(uint32_t), stream);   // atomicXor targets
         if (e != hipSuccess) return (int)e;
-        const int lds = MT_JUMP_BLOCKS * MT_N * (int)sizeof(unsigned);
+        e = hipMemcpyAsync(seg_states, state_in, MT_N * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream);
+        if (e != hipSuccess) return (int)e;
+        const int lds = (MT_JUMP_BLOCKS + 1) * MT_N * (int)sizeof(unsigned);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt19937_jump_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
         for (int m = 0; (1ll << m) < S; ++m) {                      // doubling tree over the segment start states
             const long long have = 1ll << m;
             const long long count = S - have < have ? S - have : have;
-            hipLaunchKernelGGL(mt19937_jump_kernel, dim3((unsigned)count), dim3(256), lds, stream, seg_states,
+            hipLaunchKernelGGL(mt19937_jump_kernel, dim3((unsigned)(count * MT_JUMP_SPLIT)), dim3(256), lds, stream, seg_states,
                                polys + (long long)m * MT_N, 0, (int)have);
         }
     }

@@ -193,7 +193,7 @@ def test_mt19937_jump_polynomials():
     stored_phi = int.from_bytes(z["phi"].astype("<u4").tobytes(), "little") | (int(z["phi_top"]) << (32 * 624))
     assert stored_phi == phi
     seg_words = int(z["seg_words"])
-    assert seg_words % 624 == 0 and z["polys"].shape == (8, 624)
+    assert seg_words % 624 == 0 and z["polys"].shape == (10, 624)
     for m in (0, 5):
         assert np.array_equal(z["polys"][m], J.to_words(J.x_pow_mod(seg_words << m, phi)))
     rng = np.random.default_rng(3)

@@ -22,9 +22,9 @@ import numpy as np
 
 N, M_ = 624, 397
 DEG = 19937
-SEG_BLOCKS = 4096                      # a segment = 4096 blocks of 624 words = 2,555,904 draws
+SEG_BLOCKS = 1024                      # a segment = 1024 blocks of 624 words = 638,976 draws
 SEG_WORDS = SEG_BLOCKS * N
-LEVELS = 8                             # up to 256 segments (6.5e8 draws) per call
+LEVELS = 10                            # up to 1024 segments (6.5e8 draws) per call
 
 
 def raw_words(state, nblocks):
