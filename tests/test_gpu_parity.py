@@ -586,3 +586,32 @@ def test_image_driver_default_jitter_is_the_reference_stream(dev, synthetic):
         assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
     finally:
         torch.set_rng_state(saved)
+
+
+def test_reference_rand_host_fallback(dev, monkeypatch):
+    """NERF_AMD_HOST_RNG=1 (or a torch whose generator layout fails the self-check) takes the
+    reference's own path, torch.rand(B, N).to(device): same numbers, same generator advance."""
+    from nerf_simple_amd.utils import host_rng
+    saved = torch.get_rng_state()
+    try:
+        torch.manual_seed(5)
+        st = torch.get_rng_state()
+        want = torch.rand(37, 50)
+        after = torch.rand(4)
+        for force_env in (True, False):
+            torch.set_rng_state(st)
+            if force_env:
+                monkeypatch.setenv("NERF_AMD_HOST_RNG", "1")
+            else:
+                monkeypatch.delenv("NERF_AMD_HOST_RNG", raising=False)
+                monkeypatch.setattr(host_rng, "_layout_ok", False)
+            got, pending = host_rng.reference_rand(37, 50, dev)
+            pending.finish()
+            assert torch.equal(got.cpu(), want) and torch.equal(torch.rand(4), after)
+            torch.set_rng_state(st)
+            rj = host_rng.ReferenceJitter([20, 17], 50, dev)
+            pieces = torch.cat([rj.batch(0), rj.batch(1)]).cpu()
+            rj.finish()
+            assert torch.equal(pieces, want) and torch.equal(torch.rand(4), after)
+    finally:
+        torch.set_rng_state(saved)
