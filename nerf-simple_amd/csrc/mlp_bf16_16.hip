@@ -356,15 +356,22 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
     // draws with a wave shuffle: the same numbers for half the work.
     float u_mine = 0.f;
     bool dev_rng = false;
+    long long b0 = 0;                                   // divmod(tile_base, N): wave-uniform, once per tile
+    int r0 = 0;
+    if constexpr (RAYS) {
+        b0 = tile_base / a.N;
+        r0 = (int)(tile_base - b0 * a.N);
+    }
+    const int last_local = (int)(a.P - 1 - tile_base);  // lanes past the end use the last point (results dropped)
     if constexpr (RAYS && NCB == 2) {
         dev_rng = (a.flags & NERF_FLAG_DEVICE_RNG) && !(a.flags & NERF_FLAG_TS_GIVEN);
 #if defined(NERF_EXP) && NERF_EXP == 9
         dev_rng = false;                 // A/B: every lane evaluates Philox for both of its points (the old form)
 #endif
         if (dev_rng) {
-            long long pm = tile_base + c.wave * 32 + (c.lane & 31);
-            if (pm >= a.P) pm = a.P - 1;
-            u_mine = device_rng_uniform(a, pm);
+            int lm = c.wave * 32 + (c.lane & 31);
+            if (lm > last_local) lm = last_local;
+            u_mine = device_rng_uniform(a, split_point(b0, r0, lm, a.N));
         }
     }
 #pragma unroll
@@ -376,7 +383,9 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
         PointIn pt;
         if constexpr (RAYS) {
             const float u_cb = (NCB == 2) ? __shfl(u_mine, cb * 16 + col) : 0.f;
-            pt = fetch_point_rays(a, p, u_cb, dev_rng);
+            int lp = c.wave * (16 * NCB) + cb * 16 + col;
+            if (lp > last_local) lp = last_local;
+            pt = fetch_point_rays(a, p, split_point(b0, r0, lp, a.N), u_cb, dev_rng);
             if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
         } else {
             pt = fetch_point_pts(a, p);

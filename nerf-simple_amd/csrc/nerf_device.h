@@ -107,18 +107,33 @@ struct PointIn {
 // rounded separately (__fmul_rn/__fadd_rn: no fma contraction) exactly like
 // the reference's separate torch ops, so ts and locs are bit-identical to the
 // CPU path given the same u.
-// the counter RNG's draw for global point p of this launch (FLAG_DEVICE_RNG)
-__device__ __forceinline__ float device_rng_uniform(const MlpArgs& a, long long p) {
-    const long long b = p / a.N;
-    const int i = (int)(p - b * a.N);
-    return philox_uniform(a.seed, (unsigned long long)((a.ray_id0 + b) * a.N + i));
+// (ray, sample) of point p = base + local, where (b0, r0) = divmod(base, N) is known (one wave-uniform
+// 64-bit division per tile instead of one ~80-instruction division per lane) and local < 2^16:
+// r0 + local < N + 2^16 needs only a small quotient, taken from a float reciprocal and corrected.
+struct RaySample { long long b; int i; };
+__device__ __forceinline__ RaySample split_point(long long b0, int r0, int local, int N) {
+    const unsigned tt = (unsigned)(r0 + local);
+    unsigned q = (unsigned)((float)tt * __frcp_rn((float)N));
+    if ((long long)q * N > (long long)tt) --q;                 // the float estimate is off by at most one
+    if ((long long)(q + 1) * N <= (long long)tt) ++q;
+    return RaySample{b0 + q, (int)(tt - q * (unsigned)N)};
+}
+__device__ __forceinline__ RaySample split_point(long long p, int N) {
+    const long long b = p / N;
+    return RaySample{b, (int)(p - b * N)};
+}
+
+// the counter RNG's draw for (ray b, sample i) of this launch (FLAG_DEVICE_RNG)
+__device__ __forceinline__ float device_rng_uniform(const MlpArgs& a, RaySample rs) {
+    return philox_uniform(a.seed, (unsigned long long)((a.ray_id0 + rs.b) * a.N + rs.i));
 }
 
 // u_pre: the point's device-RNG draw when the caller already has it (have_u), see mlp_bf16_16.hip stage_inputs
-__device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long p, float u_pre = 0.f, bool have_u = false) {
+__device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long p, RaySample rs, float u_pre = 0.f,
+                                                    bool have_u = false) {
     PointIn r;
-    const long long b = p / a.N;
-    const int i = (int)(p - b * a.N);
+    const long long b = rs.b;
+    const int i = rs.i;
     const float* ray = a.rays + b * 6;
     const float ox = ray[0], oy = ray[1], oz = ray[2];
     const float dx = ray[3], dy = ray[4], dz = ray[5];
@@ -144,6 +159,10 @@ __device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long 
     r.d2 = __fdiv_rn(dy, nrm);
     r.d3 = __fdiv_rn(dz, nrm);
     return r;
+}
+
+__device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long p) {
+    return fetch_point_rays(a, p, split_point(p, a.N));
 }
 
 __device__ __forceinline__ PointIn fetch_point_pts(const MlpArgs& a, long long p) {
