@@ -165,8 +165,8 @@ int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u,
 /* Training-side front end: sampling + point assembly + encoding in one launch
  * (utils/rendering.py:24-40 + utils/xyz.py:16-36): rays[B,6] (+ u / ts / device
  * RNG as in nerf_amd_render_forward) -> posx[B*N,63], posd[B*N,27], ts[B,N]
- * (Lp = 10, Ld = 4).  Feeds the dense layers when their backward runs through
- * library GEMMs. */
+ * (Lp = 10, Ld = 4).  Feeds the dense layers of the fp32 training path (autograd over
+ * library GEMMs, the path pinned against golden G6). */
 int nerf_amd_sample_encode(const float* rays, const float* u, const float* tbins,
                            uint32_t flags, uint64_t seed, int64_t ray_id0,
                            float* posx, float* posd, float* ts, int64_t B, int N, void* stream);

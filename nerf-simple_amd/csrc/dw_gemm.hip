@@ -2,12 +2,12 @@
 // reference train.py:51-54: loss.backward() as far as the 24 parameter tensors).
 //
 //   dW_l = dY_l^T @ X_l      (sum over all P = B*N query points)
-//   db_l = sum_p dY_l[p, :]  (accumulated from the A operand's staging registers of the same kernel)
+//   db_l = sum_p dY_l[p, :]  (column sums of the A operand's LDS slabs, same kernel)
 //
 // dY_l (from nerf_amd_mlp_backward) and X_l (the activations saved by
-// nerf_amd_mlp_forward_train, plus the encoder outputs) are [P, width] bf16
-// ROW-major, so both MFMA operands have the reduction index (the point) as
-// their slow dimension: a "TN" GEMM with M, N <= 256 and K = P ~ 10^5..10^6.
+// nerf_amd_mlp_forward_train, point-blocked: nerf_layout.h; plus the row-major encoder
+// outputs) have the reduction index (the point) as their slow dimension in both MFMA
+// operands: a "TN" GEMM with M, N <= 256 and K = P ~ 10^5..10^6.
 // The vendor library runs this shape on 16 workgroups; here:
 //   * ONE launch covers all 14 products; each gets a share of the ~256
 //     workgroups proportional to the bytes it streams (split-K over the points);
@@ -15,8 +15,8 @@
 //     registers and walks its K slice in slabs of 32 points, moved HBM -> LDS by
 //     LDS-DMA (no staging registers) into a 4-slot ring: three slabs (96 KiB per
 //     CU) stay in flight behind counted vmcnt waits and one raw s_barrier per slab;
-//   * the LDS image is row-major and unpadded with an XOR swizzle of the 16-byte
-//     chunks (applied to the DMA's per-lane source and to the reads);
+//   * the LDS images (one form per operand layout, below) are unpadded with an XOR
+//     swizzle of the 16-byte granules (applied to the DMA's per-lane source and to the reads);
 //   * fragments come out of LDS through ds_read_b64_tr_b16, the hardware
 //     transposing read: 4 points x 16 features in, 4 consecutive k per lane out,
 //     so no transpose pass exists anywhere;

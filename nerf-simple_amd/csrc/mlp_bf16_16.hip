@@ -178,7 +178,7 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
         dst[cb][Q] = __builtin_bit_cast(ex8, w);
         if constexpr (SAVE) {
             // the fragment is complete: write this lane's 2 x 4 features of layer L's output
-            // (row-major [P, width] bf16; features 32Q+4g.. and 32Q+16+4g..) for the backward pass
+            // (features 32Q+4g.. and 32Q+16+4g.. of its point) for the backward pass
             if (j2 == 3) {
                 // Buffer stores into this (layer, tile)'s point-blocked block (nerf_layout.h),
                 // unconditional so the vector-memory instruction count per chunk is a constant

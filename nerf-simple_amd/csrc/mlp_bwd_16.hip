@@ -10,7 +10,7 @@
 // gradient w.r.t. activations never leaves the CU.  It reads d_raw[P,4] (from
 // the compositor's backward) and the ReLU masks (one bit per feature, written by
 // the training forward in this kernel's own register layout: nerf_layout.h) and
-// writes dY_l [P, width] bf16 row-major.
+// writes dY_l (bf16, point-blocked like the saved activations).
 // The weight gradients dW_l = dY_l^T X_l are plain GEMMs over the point
 // dimension and run in dw_gemm.hip.
 //

@@ -2,15 +2,18 @@
 
 What runs where in a training step (BASELINE config 5), 16-bit precision (default):
 
-  sampling + encoding + 12 dense layers, forward    HIP  nerf_amd_mlp_forward_train (the fused
-                                                    inference kernel, also saving bf16 activations)
+  sampling + encoding + 12 dense layers, forward    HIP  nerf_amd_mlp_forward_train (the fused inference
+                                                    kernel, also saving point-blocked bf16 activations
+                                                    and ReLU mask bit planes)
   sigma -> alpha compositing, forward               HIP  nerf_amd_volume_render
   compositing, backward (suffix-sum scan)           HIP  nerf_amd_volume_render_backward
   dense layers, backward dX chain (on-chip)         HIP  nerf_amd_mlp_backward
-  dense layers, dW = dY^T X and db = sum dY         plain GEMMs / reductions over the point
-                                                    dimension: vendor library (torch.mm)
-  gradient exchange                                 RCCL all-reduce of one flat bucket (parallel.py)
-  optimizer                                         torch.optim.Adam (reference train.py:43)
+  dense layers, dW = dY^T X and db = sum dY         HIP  nerf_amd_param_gradients (one split-K launch for
+                                                    all 14 products into ONE flat gradient vector)
+  gradient exchange                                 RCCL all-reduce of that flat vector, in place (parallel.py)
+  optimizer                                         optim.FusedAdam (one launch + re-pack) or
+                                                    torch.optim.Adam (reference train.py:43)
+  the whole step as captured hipGraphs              GraphedTrainStep (below)
 
 precision='fp32' keeps everything in fp32: HIP sampling/encoding and compositor,
 the dense layers through torch.nn.functional.linear under autograd (library
@@ -112,7 +115,7 @@ def nerf_forward_autograd(net, v, precision):
 
 
 # --------------------------------------------------------------------------
-# fused dense layers: HIP forward (saving activations) + HIP dX chain + library dW
+# fused dense layers: HIP forward (saving activations) + HIP dX chain + HIP dW
 # --------------------------------------------------------------------------
 class _FusedDense(torch.autograd.Function):
     """(rays, jitter) -> raw [B,N,4], ts [B,N] through nerf_amd_mlp_forward_train;

@@ -149,7 +149,7 @@ def _grads_of(dev, synthetic, kind, precision, fused, rays, gt, u, N):
 @pytest.mark.parametrize("kind", ["default", "structured"])
 def test_fused_backward_matches_autograd(dev, synthetic, kind):
     """The hand-written training path (fused forward saving activations, HIP dX chain,
-    library dW GEMMs) against torch autograd over library GEMMs, tensor by tensor:
+    HIP dW split-K kernel) against torch autograd over library GEMMs, tensor by tensor:
     fp32 autograd is the reference; bf16 autograd shows what 8-bit mantissas cost."""
     from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
     pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
