@@ -55,9 +55,10 @@ int64_t  nerf_amd_render_workspace_bytes(int64_t B, int N);
 /* host-side self-check of the packed-weight index math (bijectivity of the
  * k-permutations, offsets, sizes); 0 = consistent.  Used by the CPU tests. */
 int      nerf_amd_layout_selfcheck(void);
-/* host-side: source column (or -1 = padding) that the packed bf16/f32 image
- * holds at (layer, k-step, lane-half, element); lets tests audit the packing. */
-int      nerf_amd_layout_src_col(int precision, int layer, int kstep, int half, int elem);
+/* host-side: source column (or -1 = padding) that the packed image holds at
+ * (layer, k-step, lane group 0..3, element 0..7 [16-bit images] / 0 [f32]); -2 = out of range.
+ * Lets tests audit the packing. */
+int      nerf_amd_layout_src_col(int precision, int layer, int kstep, int group, int elem);
 
 /* ---- weights ---------------------------------------------------------------- */
 /* Pack the 24 state-dict tensors of the reference Nerf (utils/nets.py:16-32),
@@ -106,6 +107,17 @@ int nerf_amd_volume_render_backward(const float* raw, const float* ts,
                                     const float* g_rgb, const float* g_disp, const float* g_alpha,
                                     const float* g_acc, const float* g_w,
                                     float* d_raw, int64_t B, int N, void* stream);
+
+/* Both with the directions taken from rays[B,6] and normalised inside the kernel,
+ * dirs = rays[:,3:] / ||rays[:,3:]|| as render_nerf does (utils/rendering.py:37,43):
+ * no [B,3] temporary, no extra launch (the training step uses these). */
+int nerf_amd_volume_render_rays(const float* raw, const float* ts, const float* rays,
+                                float* rgb, float* disp, float* alpha, float* acc, float* w,
+                                int64_t B, int N, void* stream);
+int nerf_amd_volume_render_rays_backward(const float* raw, const float* ts, const float* rays,
+                                         const float* g_rgb, const float* g_disp, const float* g_alpha,
+                                         const float* g_acc, const float* g_w,
+                                         float* d_raw, int64_t B, int N, void* stream);
 
 /* ---- the whole path: render_nerf, utils/rendering.py:13-45 ------------------- */
 /* rays[B,6] = [origin, direction] -> (rgb[B,3], disp[B], alpha[B,N], acc[B], w[B,N]).
@@ -165,13 +177,14 @@ int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u,
 /* Training-side front end: sampling + point assembly + encoding in one launch
  * (utils/rendering.py:24-40 + utils/xyz.py:16-36): rays[B,6] (+ u / ts / device
  * RNG as in nerf_amd_render_forward) -> posx[B*N,63], posd[B*N,27], ts[B,N]
- * (Lp = 10, Ld = 4).  Feeds the dense layers of the fp32 training path (autograd over
- * library GEMMs, the path pinned against golden G6). */
+ * (Lp = 10, Ld = 4), fp32, reference column order. */
 int nerf_amd_sample_encode(const float* rays, const float* u, const float* tbins,
                            uint32_t flags, uint64_t seed, int64_t ray_id0,
                            float* posx, float* posd, float* ts, int64_t B, int N, void* stream);
 
 /* ---- fused training path of the dense layers (reference train.py:51-54) --------
+ * bf16 ONLY: there is no fp32 / fp16 training kernel and no library fallback; a caller asking
+ * for another training precision gets NERF_AMD_EUNSUP from its host wrapper.
  * Forward as nerf_amd_mlp_forward_rays (bf16) that ALSO saves every layer's output for the
  * weight gradients (bf16; L0..L7 post-ReLU 256 features, L8 = the linear 256->256, L9 = colour
  * hidden 128; P = B*N points) in the point-blocked layout the kernels write and read with
@@ -184,6 +197,11 @@ int64_t nerf_amd_train_activation_bytes(int64_t P);
 int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* tbins,
                                const void* packed_bf16, uint32_t flags, uint64_t seed, int64_t ray_id0,
                                float* raw, float* ts, void* acts, int64_t B, int N, void* stream);
+/* The same for explicit points, i.e. Nerf.forward(v) under autograd (utils/nets.py:34-43):
+ * pts[P,6] -> out[P,4], activations saved as above; and the matching bf16 encoder rows. */
+int nerf_amd_mlp_forward_train_points(const float* pts, const void* packed_bf16, float* out,
+                                      void* acts, int64_t P, void* stream);
+int nerf_amd_encode_points_bf16(const float* pts, void* posx64, void* posd32, int64_t P, void* stream);
 /* Backward dX chain: d_raw[P,4] (from nerf_amd_volume_render_backward) + the ReLU
  * mask bits inside `acts` (the bf16 activations themselves are not read here) ->
  * dys: every layer's pre-activation gradient, bf16, point-blocked like the bf16 part
@@ -206,6 +224,12 @@ int64_t nerf_amd_param_gradients_scratch_bytes(int64_t P);
 int nerf_amd_param_gradients(const float* d_raw, const void* acts, const void* dys,
                              const void* posx64, const void* posd32, void* scratch,
                              float* grads, int64_t P, void* stream);
+
+/* ---- loss: nn.MSELoss(), reference train.py:42,52 -------------------------------- */
+/* loss[0] = mean((pred - target)^2) over n elements; g_pred[n] (may be NULL) =
+ * d loss / d pred = 2 (pred - target) / n.  One workgroup, fixed summation order. */
+int nerf_amd_mse_loss(const float* pred, const float* target, float* loss, float* g_pred,
+                      int64_t n, void* stream);
 
 /* ---- optimizer: torch.optim.Adam defaults, reference train.py:43,55 ------------- */
 /* One launch over the flat fp32 parameter vector (state_dict order; the 24 tensors are

@@ -45,6 +45,11 @@ _SIGNATURES = {
     "nerf_amd_volume_render": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_volume_render_pixels": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_volume_render_backward": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_volume_render_rays": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_volume_render_rays_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "nerf_amd_mlp_forward_train_points": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "nerf_amd_encode_points_bf16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "nerf_amd_sample_encode": (_i32, [_vp, _vp, _vp, _u32, _u64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_generate_rays": (_i32, [_vp, _i32, _i32, ctypes.c_float, _i64, _i64, _vp, _vp]),
     "nerf_amd_render_image_workspace_bytes": (_i64, [_i64, _i32]),

@@ -3,12 +3,7 @@
 // out of the kernels in this directory.  No allocation, no host sync.
 #include "nerf_device.h"
 #include "../../include/nerf_amd.h"
-#include <stdlib.h>
 #include <math.h>
-
-#ifndef NERF_AMD_DEFAULT_BF16_TILE
-#define NERF_AMD_DEFAULT_BF16_TILE 16
-#endif
 
 using namespace nerf_layout;
 
@@ -24,8 +19,8 @@ int nerf_amd_launch_generate_rays(const float*, int, int, float, long long, long
 int nerf_amd_launch_composite_backward(const float*, const float*, const float*, long long, const float*,
                                        const float*, const float*, const float*, const float*, float*,
                                        long long, int, int, hipStream_t);
+int nerf_amd_launch_mse_loss(const float*, const float*, float*, float*, long long, hipStream_t);
 int nerf_amd_launch_sample_encode(const MlpArgs*, float*, float*, hipStream_t);
-int nerf_amd_launch_mlp_bf16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f16_16(const MlpArgs*, int, hipStream_t);
@@ -47,18 +42,10 @@ inline bool bad_precision(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF1
 inline bool bad_image(int p) { return bad_precision(p) && p != NERF_AMD_BF16_BWD; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
-// bf16 has two MFMA-shape variants of the same kernel (32x32x16 and 16x16x32);
-// NERF_AMD_BF16_TILE=32|16 picks one per call (read each time: cheap, and it lets
-// one process A/B both on the same device).
-int bf16_tile() {
-    const char* e = getenv("NERF_AMD_BF16_TILE");
-    return (e && e[0] == '3') ? 32 : (e && e[0] == '1') ? 16 : NERF_AMD_DEFAULT_BF16_TILE;
-}
 int launch_mlp(const MlpArgs& a, int rays_mode, int precision, hipStream_t s) {
     if (precision == NERF_AMD_F32) return nerf_amd_launch_mlp_f32(&a, rays_mode, s);
     if (precision == NERF_AMD_FP16) return nerf_amd_launch_mlp_f16_16(&a, rays_mode, s);
-    return bf16_tile() == 16 ? nerf_amd_launch_mlp_bf16_16(&a, rays_mode, s)
-                             : nerf_amd_launch_mlp_bf16(&a, rays_mode, s);
+    return nerf_amd_launch_mlp_bf16_16(&a, rays_mode, s);
 }
 }  // namespace
 
@@ -70,9 +57,7 @@ int64_t nerf_amd_param_count(void) { return PARAM_COUNT; }
 int64_t nerf_amd_packed_bytes(int precision) {
     if (bad_image(precision)) return NERF_AMD_EINVAL;
     if (precision == NERF_AMD_BF16_BWD) return BWD_IMAGE_BYTES;
-    // + slack so that the staging loads of the last chunks stay inside the allocation
-    return precision == NERF_AMD_BF16 ? BF16_PACKED_TOTAL_BYTES
-         : precision == NERF_AMD_FP16 ? B16_IMAGE_BYTES : F32_PACKED_BYTES;
+    return precision == NERF_AMD_F32 ? F32_PACKED_BYTES : B16_IMAGE_BYTES;
 }
 
 int64_t nerf_amd_render_image_workspace_bytes(int64_t n_rays, int N) {
@@ -89,9 +74,9 @@ int64_t nerf_amd_render_workspace_bytes(int64_t B, int N) {
 
 int nerf_amd_layout_src_col(int precision, int layer, int kstep, int half, int elem) {
     if (layer < 0 || layer >= NUM_LAYERS) return -2;
-    if (precision == NERF_AMD_BF16) {
-        if (kstep < 0 || kstep >= bf16_ks(layer) || half < 0 || half > 1 || elem < 0 || elem > 7) return -2;
-        return src_col_bf16(layer, kstep, half, elem);
+    if (precision == NERF_AMD_BF16 || precision == NERF_AMD_FP16) {
+        if (kstep < 0 || kstep >= b16_ks(layer) || half < 0 || half > 3 || elem < 0 || elem > 7) return -2;
+        return src_col_b16(layer, kstep, half, elem);
     }
     if (precision == NERF_AMD_F32) {
         if (kstep < 0 || kstep >= f32_ks(layer) || half < 0 || half > 3) return -2;
@@ -103,36 +88,17 @@ int nerf_amd_layout_src_col(int precision, int layer, int kstep, int half, int e
 // Every source column of every layer must be hit exactly once by the packed
 // k positions (the permutations are bijections onto the true K, padding aside).
 int nerf_amd_layout_selfcheck(void) {
-    static_assert(BF16_WEIGHT_KIB == 1192, "bf16 image size");
-    static_assert(BIAS_FLOATS == 2496, "bias table size");
     static_assert(F32_NUM_CHUNKS == 154, "f32 chunk count");
-    static_assert(B16_WEIGHT_KIB == 1172 && B16_BIAS_FLOATS == F32_BIAS_FLOATS, "16-row bf16 image");
-    for (int L = 0; L < NUM_LAYERS; ++L) {          // 16-row bf16 tiling: same bijection property
-        const LayerDesc d = layer_desc(L);
-        int seen[320] = {0}, pads = 0;
-        for (int s = 0; s < b16_ks(L); ++s)
-            for (int g = 0; g < 4; ++g)
-                for (int j = 0; j < 8; ++j) {
-                    const int c = src_col_b16(L, s, g, j);
-                    if (c < 0) { ++pads; continue; }
-                    if (c >= d.ld) return 500 + L;
-                    ++seen[c];
-                }
-        for (int i = 0; i < d.ld; ++i)
-            if (seen[i] != 1) return 520 + L;
-        if (pads != layer_k(L) - d.ld) return 540 + L;
-    }
+    static_assert(B16_WEIGHT_KIB == 1172 && B16_BIAS_FLOATS == F32_BIAS_FLOATS, "16-row 16-bit image");
     for (int L = 0; L < NUM_LAYERS; ++L) {
         const LayerDesc d = layer_desc(L);
-        int seen[320];
-        for (int prec = 0; prec < 2; ++prec) {
-            for (int i = 0; i < 320; ++i) seen[i] = 0;
-            int pads = 0;
-            if (prec == NERF_AMD_BF16) {
-                for (int s = 0; s < bf16_ks(L); ++s)
-                    for (int h = 0; h < 2; ++h)
+        for (int prec = 0; prec < 2; ++prec) {          // 0: f32 k order, 1: 16-bit k order
+            int seen[320] = {0}, pads = 0;
+            if (prec == 1) {
+                for (int s = 0; s < b16_ks(L); ++s)
+                    for (int g = 0; g < 4; ++g)
                         for (int j = 0; j < 8; ++j) {
-                            const int c = src_col_bf16(L, s, h, j);
+                            const int c = src_col_b16(L, s, g, j);
                             if (c < 0) { ++pads; continue; }
                             if (c >= d.ld) return 100 + L;
                             ++seen[c];
@@ -200,6 +166,30 @@ int nerf_amd_volume_render_pixels(const float* raw, const float* ts, const float
     if (!raw || !ts || !rays || !pixels) return NERF_AMD_EINVAL;
     return nerf_amd_launch_composite(raw, ts, rays + 3, 6, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, 1,
                                      pixels, S(stream));
+}
+
+int nerf_amd_volume_render_rays(const float* raw, const float* ts, const float* rays, float* rgb, float* disp,
+                                float* alpha, float* acc, float* w, int64_t B, int N, void* stream) {
+    if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (!raw || !ts || !rays || !rgb || !disp || !acc) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_composite(raw, ts, rays + 3, 6, rgb, disp, alpha, acc, w, B, N, 1, nullptr, S(stream));
+}
+
+int nerf_amd_volume_render_rays_backward(const float* raw, const float* ts, const float* rays, const float* g_rgb,
+                                         const float* g_disp, const float* g_alpha, const float* g_acc,
+                                         const float* g_w, float* d_raw, int64_t B, int N, void* stream) {
+    if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (N > 512) return NERF_AMD_EUNSUP;
+    if (!raw || !ts || !rays || !d_raw) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_composite_backward(raw, ts, rays + 3, 6, g_rgb, g_disp, g_alpha, g_acc, g_w, d_raw, B, N, 1,
+                                              S(stream));
+}
+
+int nerf_amd_mse_loss(const float* pred, const float* target, float* loss, float* g_pred, int64_t n, void* stream) {
+    if (n <= 0 || !pred || !target || !loss) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_mse_loss(pred, target, loss, g_pred, n, S(stream));
 }
 
 int nerf_amd_volume_render_backward(const float* raw, const float* ts, const float* dirs, int64_t dirs_stride,
@@ -314,6 +304,25 @@ int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* t
     a.rays = rays; a.u = u; a.tbins = tbins; a.packed = packed; a.raw = raw; a.ts_out = ts; a.acts = acts;
     a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
     return nerf_amd_launch_mlp_bf16_16(&a, 1, S(stream));
+}
+
+int nerf_amd_mlp_forward_train_points(const float* pts, const void* packed, float* out, void* acts, int64_t P,
+                                      void* stream) {
+    if (P < 0) return NERF_AMD_EINVAL;
+    if (P == 0) return 0;
+    if (!pts || !packed || !out || !acts) return NERF_AMD_EINVAL;
+    MlpArgs a{};
+    a.pts = pts; a.packed = packed; a.raw = out; a.acts = acts; a.P = P; a.N = 1;
+    return nerf_amd_launch_mlp_bf16_16(&a, 1, S(stream));
+}
+
+int nerf_amd_encode_points_bf16(const float* pts, void* posx64, void* posd32, int64_t P, void* stream) {
+    if (P < 0) return NERF_AMD_EINVAL;
+    if (P == 0) return 0;
+    if (!pts || !posx64 || !posd32) return NERF_AMD_EINVAL;
+    MlpArgs a{};
+    a.pts = pts; a.P = P; a.N = 1;
+    return nerf_amd_launch_sample_encode_bf16(&a, posx64, posd32, S(stream));
 }
 
 int nerf_amd_mlp_backward(const float* d_raw, const void* bwd_image, const void* acts, void* dys, int64_t P,

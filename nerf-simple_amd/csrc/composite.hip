@@ -226,6 +226,28 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_backward_kernel
     }
 }
 
+// ---- MSELoss(pred, target) and its gradient (reference train.py:52: mean over all n elements) ----
+// One workgroup, fixed summation order: the loss is bit-reproducible from run to run.
+__global__ __launch_bounds__(1024) void mse_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        float* __restrict__ loss, float* __restrict__ g_pred, long long n) {
+    __shared__ float red[16];
+    const float inv_n = 1.0f / (float)n;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < n; i += 1024) {
+        const float d = pred[i] - target[i];
+        s += d * d;
+        if (g_pred) g_pred[i] = 2.0f * d * inv_n;
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 16; ++k) t += red[k];
+        *loss = t * inv_n;
+    }
+}
+
 }  // namespace
 
 extern "C" int nerf_amd_launch_composite_backward(const float* raw, const float* ts, const float* dirs,
@@ -252,5 +274,12 @@ extern "C" int nerf_amd_launch_composite(const float* raw, const float* ts, cons
     const long long blocks = (B + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
     hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_BLOCK), 0, stream,
                        raw, ts, dirs, dirs_stride, rgb, disp, alpha, acc, w, B, N, normalize_dirs, pixels);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nerf_amd_launch_mse_loss(const float* pred, const float* target, float* loss, float* g_pred, long long n,
+                                        hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(1024), 0, stream, pred, target, loss, g_pred, n);
     return (int)hipGetLastError();
 }

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void sample_encode_bf16_kernel(MlpArgs a, __bf
                                                                  __bf16* __restrict__ posd) {
     const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
     if (p >= a.P) return;
-    const PointIn pt = fetch_point_rays(a, p);
+    const PointIn pt = a.pts ? fetch_point_pts(a, p) : fetch_point_rays(a, p);      // points mode: Nerf.forward(v)
     if (a.ts_out) a.ts_out[p] = pt.t;
     {
         __bf16 row[64];

@@ -1,61 +1,45 @@
-// mlp_bf16_16.hip -- the fused bf16 MLP on v_mfma_f32_16x16x32_bf16.
+// mlp_bf16_16.hip -- the fused 16-bit MLP: sampling + positional encoding + 12 dense layers in
+// one launch, on v_mfma_f32_16x16x32_bf16 (and, built with -DNERF_HALF, on ..._f16).
+// Replaces reference utils/rendering.py:24-40 + utils/xyz.py:6-36 + utils/nets.py:34-43.
 //
-// Same algorithm, tile and dataflow as mlp_bf16.hip (read its header first);
-// only the MFMA shape differs: 16-row output tiles, a wave's 32 points are two
-// 16-point column blocks, 64 lanes = 16 points x 4 lane groups.  The chip is
-// power/DVFS-limited on this kernel and holds a higher
-// clock on the 16x16x32 shape than on 32x32x16 at equal cycles per FLOP
-// (MI355X_MICROARCH.md, DVFS give-back item 7), so this variant exists to be
-// A/B'd against the 32x32x16 one on the same device.
-//
-//   * two stacked 16-row accumulator tiles (2q, 2q+1), converted to bf16, ARE
-//     the B fragment of the next layer's k-step q (32 features);
-//   * one weight fragment read from LDS (16 rows x 32 k, 1 KiB) feeds two
-//     MFMAs (the two column blocks): the same LDS bytes per FLOP;
-//   * the sigma head costs one 16-row tile and the rgb head 8 MFMAs (half of
-//     the 32-row variant's padding).
+// H^T = W . X^T: output features on MFMA rows, points on MFMA columns / lanes (nerf_layout.h).
+//   * a wave owns 32 points = two 16-point column blocks; 64 lanes = 16 points x 4 lane groups;
+//   * two stacked 16-row accumulator tiles (2q, 2q+1), bias-initialised, ReLU'd and converted
+//     pairwise, ARE the B fragment of the next layer's k-step q (32 features): activations never
+//     leave the registers;
+//   * weights stream L2 -> LDS by LDS-DMA in chunks of four 16-row tiles, double buffered, one
+//     barrier per chunk; one weight fragment read from LDS (16 rows x 32 k, 1 KiB) feeds two
+//     MFMAs (the two column blocks);
+//   * the sigma head rides as row 256 of the layers_2 product, the rgb head is one 16-row tile;
+//   * a workgroup = 8 waves = a 256-point tile, persistent over tiles.
+// The chip is power/DVFS-limited on this kernel and holds a higher clock on the 16x16x32 shape
+// than on 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back item 7).
 #include "nerf_device.h"
 #include <utility>
 
 using namespace nerf_layout;
 
 // The same source builds the bf16 kernel (default) and, with -DNERF_HALF, the
-// fp16 one (v_mfma_f32_16x16x32_f16: same rate, 11-bit mantissa instead of 8).
+// fp16 one (v_mfma_f32_16x16x32_f16: same cycles, 11-bit mantissa instead of 8).
 #ifdef NERF_HALF
 typedef _Float16 elem_t;
 #define NERF_MFMA __builtin_amdgcn_mfma_f32_16x16x32_f16
 #define NERF_KERNEL nerf_mlp_f16_16_kernel
 #define NERF_LAUNCH nerf_amd_launch_mlp_f16_16
-static constexpr long long IMG_OFFSET = 0;                  // the fp16 packed buffer holds only this image
-#elif defined(NERF_EXP)
-// experiment slot: built by `make EXP=1` INSTEAD of mlp_bf16.hip under that kernel's launcher
-// name, so NERF_AMD_BF16_TILE=32 selects it and tools/ab_bench.py A/Bs it against the default
-typedef __bf16 elem_t;
-#define NERF_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
-#define NERF_KERNEL nerf_mlp_bf16_exp_kernel
-#define NERF_LAUNCH nerf_amd_launch_mlp_bf16
-static constexpr long long IMG_OFFSET = nerf_layout::B16_IMAGE_OFFSET;
 #else
 typedef __bf16 elem_t;
 #define NERF_MFMA __builtin_amdgcn_mfma_f32_16x16x32_bf16
 #define NERF_KERNEL nerf_mlp_bf16_16_kernel
 #define NERF_LAUNCH nerf_amd_launch_mlp_bf16_16
-static constexpr long long IMG_OFFSET = nerf_layout::B16_IMAGE_OFFSET;
 #endif
 typedef elem_t ex8 __attribute__((ext_vector_type(8)));
 typedef elem_t ex2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
-// NCB 16-point column blocks per wave: 2 (8 waves, 2 per SIMD, <= 256 registers each; default) or
-// 4 (4 waves, 1 per SIMD, accumulators in AGPRs: every weight fragment read from LDS feeds 4 MFMAs)
-#ifndef NERF_AHEAD
-#define NERF_AHEAD 4
-#endif
-#ifndef NERF_NCB
-#define NERF_NCB 2
-#endif
-constexpr int NCB = NERF_NCB;
+// NCB 16-point column blocks per wave: 8 waves (2 per SIMD) x 2 blocks.  (4 waves x 4 blocks with
+// the accumulators in AGPRs halves the LDS weight reads but measured 4.5 % slower: DESIGN.md section 5.)
+constexpr int NCB = 2;
 constexpr int WAVES = 16 / NCB;
 constexpr int TILE_PTS = WAVES * 16 * NCB;
 constexpr int TPC = 4;                        // 16-row output tiles per weight chunk (64 rows)
@@ -232,7 +216,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
     constexpr int NT = chunk_tiles(CC);
     constexpr int RT0 = C * TPC;
     constexpr int F = NT * KS;                      // weight fragments (each feeds 2 MFMAs)
-    constexpr int AHEAD = NERF_AHEAD;                // weight fragments in flight ahead of their MFMAs
+    constexpr int AHEAD = 4;                         // weight fragments in flight ahead of their MFMAs (2..8 measure alike)
     constexpr int BIAS_OFF = LDS_BIAS + (b16_bias_off(L) + 16 * RT0) * 4;
     constexpr int XBLK = D.extra_kind == 1 ? 2048 : 1024;
     // chunk-linear MFMA index m = (t*KS + ks)*2 + cb
@@ -246,9 +230,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
     const unsigned wb = c.b_wread[CC & 1];
     const unsigned xb = D.extra_kind == 1 ? c.b_posx : c.b_posd;
 
-#if !defined(NERF_EXP) || NERF_EXP != 4
-    Stage<CC>::issue(c);            // (ablation NERF_EXP=4: no weight DMA; results are garbage)
-#endif
+    Stage<CC>::issue(c);
     __builtin_amdgcn_sched_barrier(0);   // every other vector-memory instruction of the chunk stays behind the DMA
 
     ex8 a[AHEAD];
@@ -311,16 +293,8 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
         st.pend[cb][0] = acc[cb][NT >= 2 ? NT - 2 : 0];
         st.pend[cb][1] = acc[cb][NT - 1];
     }
-#if defined(NERF_EXP) && NERF_EXP == 3
-    // ablation: no chunk barrier (races: results are garbage; timing only)
-#elif defined(NERF_EXP) && NERF_EXP == 5
-    // A/B: the fenced barrier used before chunk_barrier existed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#else
     // this wave's LDS-DMA pieces (issued first in this chunk) have landed; the stores behind them may fly on
     chunk_barrier<pair_vmem_ops<SAVE>(PL, PQ) + (NT == 4 ? pair_vmem_ops<SAVE>(L, 2 * C) : 0)>();
-#endif
 }
 
 __host__ __device__ constexpr int prev_layer(int L, int C) { return C > 0 ? L : L - 1; }
@@ -347,7 +321,9 @@ __device__ __forceinline__ float enc_lane(TwoF q, int idx) {
     return __builtin_amdgcn_sinf(fr);
 }
 
-template <bool RAYS>
+// SAVE (the training forward, launched in rays mode) also serves Nerf.forward(v) with gradients:
+// a.pts != NULL switches the point fetch at run time, so training needs no third instantiation.
+template <bool RAYS, bool SAVE>
 __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base, State& st) {
     const int col = c.lane & 15, g = c.lane >> 4;
     // Counter-RNG jitter: the four lane groups of a point would each evaluate the same Philox
@@ -365,9 +341,6 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
     const int last_local = (int)(a.P - 1 - tile_base);  // lanes past the end use the last point (results dropped)
     if constexpr (RAYS && NCB == 2) {
         dev_rng = (a.flags & NERF_FLAG_DEVICE_RNG) && !(a.flags & NERF_FLAG_TS_GIVEN);
-#if defined(NERF_EXP) && NERF_EXP == 9
-        dev_rng = false;                 // A/B: every lane evaluates Philox for both of its points (the old form)
-#endif
         if (dev_rng) {
             int lm = c.wave * 32 + (c.lane & 31);
             if (lm > last_local) lm = last_local;
@@ -385,8 +358,12 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
             const float u_cb = (NCB == 2) ? __shfl(u_mine, cb * 16 + col) : 0.f;
             int lp = c.wave * (16 * NCB) + cb * 16 + col;
             if (lp > last_local) lp = last_local;
-            pt = fetch_point_rays(a, p, split_point(b0, r0, lp, a.N), u_cb, dev_rng);
-            if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
+            if (SAVE && a.pts) {
+                pt = fetch_point_pts(a, p);
+            } else {
+                pt = fetch_point_rays(a, p, split_point(b0, r0, lp, a.N), u_cb, dev_rng);
+                if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
+            }
         } else {
             pt = fetch_point_pts(a, p);
         }
@@ -434,7 +411,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
     Ctx c;
     c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.lane = threadIdx.x & 63;
-    const char* img = reinterpret_cast<const char*>(a.packed) + IMG_OFFSET;
+    const char* img = reinterpret_cast<const char*>(a.packed);
     c.wrsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(img), 0, (int)B16_IMAGE_BYTES, 0x00020000);
     c.wave_goff = c.wave * 1024;
     c.lane16 = c.lane * 16;
@@ -464,13 +441,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
         st.P = a.P;
         st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
         st.tile = tile;
-#if defined(NERF_EXP) && NERF_EXP == 6
-        // ablation: the tile prologue (ray loads, RNG, encoding) only for the first tile; timing only
-        if (tile == (long long)blockIdx.x) stage_inputs<RAYS>(c, a, tile_base, st);
-        else { for (int cb_ = 0; cb_ < NCB; ++cb_) st.loff[cb_] = LOFF_INVALID; }
-#else
-        stage_inputs<RAYS>(c, a, tile_base, st);
-#endif
+        stage_inputs<RAYS, SAVE>(c, a, tile_base, st);
 
         run_layer<0, SAVE>(c, st, st.X, st.X);
         run_layer<1, SAVE>(c, st, st.X, st.Y);
@@ -516,7 +487,7 @@ extern "C" int NERF_LAUNCH(const MlpArgs* args, int rays_mode, hipStream_t strea
     if (a.acts) return -2;                       // the training forward exists in bf16 only
     auto kern = rays_mode ? NERF_KERNEL<true, false> : NERF_KERNEL<false, false>;
 #else
-    if (a.acts && !rays_mode) return -2;
+    if (a.acts && !rays_mode) return -2;          // the training forward is the rays-mode instantiation (a.pts selects points)
     auto kern = a.acts ? NERF_KERNEL<true, true>
                        : (rays_mode ? NERF_KERNEL<true, false> : NERF_KERNEL<false, false>);
 #endif

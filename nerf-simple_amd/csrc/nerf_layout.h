@@ -17,7 +17,7 @@
 //   L10     128                           -> 32   none   rows 0..2 color_fc.2, rest 0
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define NL_HD __host__ __device__
 #else
 #define NL_HD
@@ -76,13 +76,6 @@ NL_HD constexpr LayerDesc layer_desc(int L) {
 NL_HD constexpr int layer_k(int L) { return layer_desc(L).chain_k + layer_desc(L).extra_slots; }
 
 // ---- k-permutations -------------------------------------------------------
-// bf16, mfma_f32_32x32x16_bf16: k-step s covers 16 k's; lane half h = lane>>5
-// holds elements j = 0..7.  An accumulator register r of a 32-row tile holds
-// row (r&3) + 8(r>>2) + 4h, so registers 8s..8s+7 converted to bf16 ARE the
-// fragment of k-step s with this feature order:
-NL_HD constexpr int chain_feat_bf16(int s, int h, int j) {
-    return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-}
 // f32, mfma_f32_16x16x4f32 (16-row tiles): k-step s covers 4 k's, one per lane
 // group g = lane>>4.  Accumulator register i of 16-row tile t holds row 4g + i,
 // so that register IS k-step 4t + i of the next layer:
@@ -90,25 +83,8 @@ NL_HD constexpr int chain_feat_f32(int s, int g) {
     return 16 * (s >> 2) + 4 * g + (s & 3);
 }
 
-// posx slots: each lane half evaluates 15 (coord, level) sin/cos pairs with a
-// STATIC coordinate and a level that is static + 5h, so the encoder needs no
-// per-lane selects.  slot t in [0,32) of half h -> source column of posx
-// (reference utils/xyz.py:33: [x,y,z, g(x)(20), g(y)(20), g(z)(20)], g = sin,cos
-// interleaved per level) or -1 for zero padding.
-NL_HD constexpr int posx_col(int t, int h) {
-    return t < 30 ? 3 + 20 * ((t >> 1) / 5) + 2 * (5 * h + (t >> 1) % 5) + (t & 1)
-         : t == 30 ? (h == 0 ? 0 : 2)
-         :           (h == 0 ? 1 : -1);
-}
-// posd slots t in [0,16) of half h (Ld = 4: 8 columns per coordinate)
-NL_HD constexpr int posd_col(int t, int h) {
-    return t < 12 ? 3 + 8 * ((t >> 1) / 2) + 2 * (2 * h + (t >> 1) % 2) + (t & 1)
-         : t == 12 ? (h == 0 ? 0 : 2)
-         : t == 13 ? (h == 0 ? 1 : -1)
-         :           -1;
-}
-
-// f32 slots (4 lane groups): group g evaluates, per coordinate, the five
+// posx / posd slots (4 lane groups, shared by the f32 and the 16-bit kernels):
+// group g evaluates, per coordinate, the five
 // (level, trig) pairs idx = 5g..5g+4 of the 20 (idx = 2*level + trig), and one
 // raw coordinate.  slot t in [0,16).
 NL_HD constexpr int posx_col_f32(int t, int g) {
@@ -122,16 +98,7 @@ NL_HD constexpr int posd_col_f32(int t, int g) {
          :          -1;
 }
 
-// source column of layer L's weight for MFMA k position, bf16 form:
-// ks = k-step (16 k's each) over [chain part | extra part]
-NL_HD constexpr int src_col_bf16(int L, int ks, int h, int j) {
-    const LayerDesc d = layer_desc(L);
-    const int chain_ks = d.chain_k / 16;
-    if (ks < chain_ks) return chain_feat_bf16(ks, h, j);
-    const int t = 8 * (ks - chain_ks) + j;
-    const int c = d.extra_kind == 1 ? posx_col(t, h) : posd_col(t, h);
-    return c < 0 ? -1 : d.extra_col0 + c;
-}
+// source column of layer L's weight for MFMA k position,
 // f32 form: ks = k-step (4 k's each), g = lane group
 NL_HD constexpr int src_col_f32(int L, int ks, int g) {
     const LayerDesc d = layer_desc(L);
@@ -160,30 +127,7 @@ NL_HD inline float bias_at(const T* params, int L, int row) {
     return params[d.b_off + row];
 }
 
-// ---- packed bf16 image ----------------------------------------------------
-// chunk = (layer, 32-row output tile m): KS fragments of 1 KiB
-// (64 lanes x 8 bf16, lane-linear so that one ds_read_b128 / dwordx4 per lane
-// fetches a fragment), padded to a multiple of 4 KiB so the 4 waves of a
-// workgroup each move the same number of 1 KiB pieces.
-NL_HD constexpr int bf16_ks(int L) { return layer_k(L) / 16; }
-NL_HD constexpr int bf16_chunk_kib(int L) { return (bf16_ks(L) + 3) / 4 * 4; }
-NL_HD constexpr int bf16_layer_off_kib(int L) {
-    int o = 0;
-    for (int i = 0; i < L; ++i) o += layer_desc(i).mt * bf16_chunk_kib(i);
-    return o;
-}
-constexpr int BF16_WEIGHT_KIB = bf16_layer_off_kib(NUM_LAYERS);      // 1192
-NL_HD constexpr int bias_off(int L) {       // in floats, into the bias table
-    int o = 0;
-    for (int i = 0; i < L; ++i) o += layer_desc(i).mt * 32;
-    return o;
-}
-constexpr int BIAS_FLOATS = bias_off(NUM_LAYERS);                    // 2496
-constexpr long long BF16_PACKED_BYTES = (long long)BF16_WEIGHT_KIB * 1024 + BIAS_FLOATS * 4;
-constexpr int BF16_MAX_CHUNK_KIB = 20;
-constexpr int NUM_CHUNKS = 8 * 8 + 9 + 4 + 1;                        // 78
-
-// ---- packed bf16 image, 16-row tiles (v_mfma_f32_16x16x32_bf16 variant) ----------
+// ---- packed 16-bit image, 16-row tiles (v_mfma_f32_16x16x32_bf16 / _f16) ----------
 // A wave's 64 lanes are 16 points x 4 lane groups g; a k-step covers 32 k's,
 // lane group g holding elements j = 0..7 (hardware k = 8g + j).  Two stacked
 // 16-row accumulator tiles (2q, 2q+1) give lane (c,g) rows 4g..4g+3 of each:
@@ -214,11 +158,8 @@ NL_HD constexpr int b16_bias_off(int L) {
     return o;
 }
 constexpr int B16_BIAS_FLOATS = b16_bias_off(NUM_LAYERS);            // 2464
-// the bf16 packed buffer holds both tilings back to back (the kernel variant is
-// chosen at launch): [32-row image | its bias | 16-row image | its bias]
-constexpr long long B16_IMAGE_OFFSET = ((long long)BF16_WEIGHT_KIB * 1024 + BIAS_FLOATS * 4 + 1023) / 1024 * 1024;
+// the packed 16-bit buffer (bf16 or fp16): [weight image | bias table (fp32, natural row order)]
 constexpr long long B16_IMAGE_BYTES = (long long)B16_WEIGHT_KIB * 1024 + B16_BIAS_FLOATS * 4;
-constexpr long long BF16_PACKED_TOTAL_BYTES = B16_IMAGE_OFFSET + B16_IMAGE_BYTES;
 
 // ---- backward (dX chain) image, bf16, 16-row tiles -------------------------------
 // Training backward of the dense layers: dX = W^T dY.  The same on-chip chaining
@@ -304,11 +245,11 @@ NL_HD constexpr long long acts_total_bytes(long long P) { return acts_bf16_bytes
 // ---- packed f32 image -----------------------------------------------------
 // 16-row output tiles (mfma_f32_16x16x4f32).  chunk = (layer, t): K/4 k-steps
 // x 64 lanes x 4 B, stored [ks/4][lane][4] so one ds_read_b128 per lane covers
-// 4 consecutive k-steps.  A chunk is K*64 bytes -- the same size as the bf16
-// chunk of the same layer, so both kernels share the staging geometry.
+// 4 consecutive k-steps.  A chunk is K*64 bytes, padded to a multiple of 4 KiB so
+// the 4 waves of a workgroup each move the same number of 1 KiB pieces.
 NL_HD constexpr int f32_mt(int L) { return L == 8 ? 17 : L == 10 ? 1 : layer_desc(L).mt * 2; }
 NL_HD constexpr int f32_ks(int L) { return layer_k(L) / 4; }
-NL_HD constexpr int f32_chunk_kib(int L) { return bf16_chunk_kib(L); }
+NL_HD constexpr int f32_chunk_kib(int L) { return (layer_k(L) / 16 + 3) / 4 * 4; }
 NL_HD constexpr int f32_layer_off_kib(int L) {
     int o = 0;
     for (int i = 0; i < L; ++i) o += f32_mt(i) * f32_chunk_kib(i);

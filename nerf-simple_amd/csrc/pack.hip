@@ -7,28 +7,7 @@ using namespace nerf_layout;
 
 namespace {
 
-// bf16 image: [chunk (layer, m)][k-step s][lane][8 bf16]; see nerf_layout.h
-__global__ void pack_bf16_kernel(const float* __restrict__ params, __bf16* __restrict__ out) {
-    const long long total = (long long)BF16_WEIGHT_KIB * 512;     // bf16 elements
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        const int kib = (int)(e >> 9);
-        int L = 0;
-        while (L + 1 < NUM_LAYERS && kib >= bf16_layer_off_kib(L + 1)) ++L;
-        const int rel = kib - bf16_layer_off_kib(L);
-        const int ck = bf16_chunk_kib(L);
-        const int m = rel / ck, s = rel % ck;
-        const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
-        float v = 0.f;
-        if (s < bf16_ks(L)) {
-            const int row = 32 * m + (lane & 31), h = lane >> 5;
-            v = weight_at(params, L, row, src_col_bf16(L, s, h, j));
-        }
-        out[e] = (__bf16)v;
-    }
-}
-
-// bf16 image, 16-row tiles: [tile (layer, rt)][k-step][lane][8 bf16]
+// 16-bit image (bf16 or fp16), 16-row tiles: [tile (layer, rt)][k-step][lane][8 elements]
 template <class T>
 __global__ void pack_b16_kernel(const float* __restrict__ params, T* __restrict__ out) {
     const long long total = (long long)B16_WEIGHT_KIB * 512;
@@ -84,18 +63,13 @@ __global__ void pack_f32_kernel(const float* __restrict__ params, float* __restr
     }
 }
 
-// bias tables: natural row order, padded to whole tiles
-__global__ void pack_bias_kernel(const float* __restrict__ params, float* __restrict__ out, int f32_tiles) {
-    const int total = f32_tiles ? F32_BIAS_FLOATS : BIAS_FLOATS;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+// bias table: natural row order, 16 rows per tile (the 16-bit and the f32 kernels share it)
+__global__ void pack_bias_kernel(const float* __restrict__ params, float* __restrict__ out) {
+    static_assert(B16_BIAS_FLOATS == F32_BIAS_FLOATS, "one bias table layout");
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F32_BIAS_FLOATS; e += gridDim.x * blockDim.x) {
         int L = 0;
-        if (f32_tiles) {
-            while (L + 1 < NUM_LAYERS && e >= f32_bias_off(L + 1)) ++L;
-            out[e] = bias_at(params, L, e - f32_bias_off(L));
-        } else {
-            while (L + 1 < NUM_LAYERS && e >= bias_off(L + 1)) ++L;
-            out[e] = bias_at(params, L, e - bias_off(L));
-        }
+        while (L + 1 < NUM_LAYERS && e >= f32_bias_off(L + 1)) ++L;
+        out[e] = bias_at(params, L, e - f32_bias_off(L));
     }
 }
 
@@ -103,32 +77,25 @@ __global__ void pack_bias_kernel(const float* __restrict__ params, float* __rest
 
 extern "C" int nerf_amd_launch_pack(const float* params, void* packed, int precision, hipStream_t stream) {
     (void)hipGetLastError();   // drop any stale error: the return value is about THIS launch
-    if (precision == 1) {
-        hipLaunchKernelGGL(pack_bf16_kernel, dim3(1024), dim3(256), 0, stream, params,
-                           reinterpret_cast<__bf16*>(packed));
-        float* bias = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + (long long)BF16_WEIGHT_KIB * 1024);
-        hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params, bias, 0);
-        char* img16 = reinterpret_cast<char*>(packed) + B16_IMAGE_OFFSET;
-        hipLaunchKernelGGL(pack_b16_kernel<__bf16>, dim3(1024), dim3(256), 0, stream, params,
-                           reinterpret_cast<__bf16*>(img16));
-        // 16-row bias table == the f32 path's (natural row order, 16 per tile)
+    char* img = reinterpret_cast<char*>(packed);
+    if (precision == 1 || precision == 2) {
+        if (precision == 1)
+            hipLaunchKernelGGL(pack_b16_kernel<__bf16>, dim3(1024), dim3(256), 0, stream, params,
+                               reinterpret_cast<__bf16*>(img));
+        else
+            hipLaunchKernelGGL(pack_b16_kernel<_Float16>, dim3(1024), dim3(256), 0, stream, params,
+                               reinterpret_cast<_Float16*>(img));
         hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params,
-                           reinterpret_cast<float*>(img16 + (long long)B16_WEIGHT_KIB * 1024), 1);
+                           reinterpret_cast<float*>(img + (long long)B16_WEIGHT_KIB * 1024));
     } else if (precision == 3) {
         // training backward image (bf16)
         hipLaunchKernelGGL(pack_bwd_kernel, dim3(1024), dim3(256), 0, stream, params,
-                           reinterpret_cast<__bf16*>(packed));
-    } else if (precision == 2) {
-        // fp16: the 16-row image only, at offset 0
-        hipLaunchKernelGGL(pack_b16_kernel<_Float16>, dim3(1024), dim3(256), 0, stream, params,
-                           reinterpret_cast<_Float16*>(packed));
-        hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params,
-                           reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + (long long)B16_WEIGHT_KIB * 1024), 1);
+                           reinterpret_cast<__bf16*>(img));
     } else {
         hipLaunchKernelGGL(pack_f32_kernel, dim3(1024), dim3(256), 0, stream, params,
-                           reinterpret_cast<float*>(packed));
-        float* bias = reinterpret_cast<float*>(reinterpret_cast<char*>(packed) + (long long)F32_WEIGHT_KIB * 1024);
-        hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params, bias, 1);
+                           reinterpret_cast<float*>(img));
+        hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params,
+                           reinterpret_cast<float*>(img + (long long)F32_WEIGHT_KIB * 1024));
     }
     return (int)hipGetLastError();
 }

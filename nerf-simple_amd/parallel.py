@@ -93,6 +93,16 @@ def flat_grad_view(params):
     return torch.as_strided(g0, (off - start,), (1,), start)
 
 
+def allreduce_flat_(flat, group=None):
+    """In-place mean over the data-parallel replicas of ONE flat gradient vector (the fused
+    backward's 2.38 MB bucket): a single all-reduce, then a scale."""
+    rank, world = world_info(group)
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= world
+    return flat
+
+
 def allreduce_gradients(params, group=None):
     """Average gradients over data-parallel replicas with ONE collective: the
     grads are flattened into a single contiguous bucket (2.38 MB for the NeRF
@@ -105,8 +115,7 @@ def allreduce_gradients(params, group=None):
         return
     flat = flat_grad_view(params)
     if flat is not None:                       # the fused backward's flat vector: reduce it in place
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat /= world
+        allreduce_flat_(flat, group=group)
         return
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

@@ -1,26 +1,27 @@
 """Training-side entry points: the step of reference train.py:47-57 on the GPU.
 
-What runs where in a training step (BASELINE config 5), 16-bit precision (default):
+What runs where in a training step (BASELINE config 5); every stage is a hand-written HIP kernel
+behind the C ABI, torch supplies tensors, streams, autograd bookkeeping and the collective:
 
-  sampling + encoding + 12 dense layers, forward    HIP  nerf_amd_mlp_forward_train (the fused inference
+  sampling + encoding + 12 dense layers, forward    nerf_amd_mlp_forward_train (the fused inference
                                                     kernel, also saving point-blocked bf16 activations
                                                     and ReLU mask bit planes)
-  sigma -> alpha compositing, forward               HIP  nerf_amd_volume_render
-  compositing, backward (suffix-sum scan)           HIP  nerf_amd_volume_render_backward
-  dense layers, backward dX chain (on-chip)         HIP  nerf_amd_mlp_backward
-  dense layers, dW = dY^T X and db = sum dY         HIP  nerf_amd_param_gradients (one split-K launch for
+  sigma -> alpha compositing, forward               nerf_amd_volume_render
+  MSE loss and its gradient                         nerf_amd_mse_loss (GraphedTrainStep) / torch (eager)
+  compositing, backward (suffix-sum scan)           nerf_amd_volume_render_backward
+  dense layers, backward dX chain (on-chip)         nerf_amd_mlp_backward
+  dense layers, dW = dY^T X and db = sum dY         nerf_amd_param_gradients (one split-K launch for
                                                     all 14 products into ONE flat gradient vector)
   gradient exchange                                 RCCL all-reduce of that flat vector, in place (parallel.py)
   optimizer                                         optim.FusedAdam (one launch + re-pack) or
                                                     torch.optim.Adam (reference train.py:43)
   the whole step as captured hipGraphs              GraphedTrainStep (below)
 
-precision='fp32' keeps everything in fp32: HIP sampling/encoding and compositor,
-the dense layers through torch.nn.functional.linear under autograd (library
-GEMMs); that path is the one pinned bit-tight against golden G6.  Inference never
-comes here: without gradients the fused forward kernel runs.
+Precision: the training kernels exist in bf16 only (gradients need bf16's exponent range; fp16
+would need loss scaling).  A module built with precision='bf16' or 'fp16' trains through them --
+``precision`` selects the INFERENCE kernel only -- and precision='fp32' raises: there is no fp32
+training path and no library-GEMM fallback (include/nerf_amd.h: NERF_AMD_EUNSUP).
 """
-import os
 
 import torch
 import torch.nn.functional as F
@@ -48,8 +49,11 @@ def img_psnr(gt, pred):
 # compositor with a HIP backward
 # --------------------------------------------------------------------------
 class _VolumeRender(torch.autograd.Function):
+    """volume_render with the HIP backward.  ``from_rays``: ``dirs`` is the [B,6] ray table and the
+    kernels normalise rays[:,3:] themselves (render_nerf, utils/rendering.py:37,43)."""
+
     @staticmethod
-    def forward(ctx, raw, ts, dirs):
+    def forward(ctx, raw, ts, dirs, from_rays):
         B, N = raw.shape[0], raw.shape[1]
         dev = raw.device
         raw, ts, dirs = raw.contiguous(), ts.contiguous(), dirs.contiguous()
@@ -58,12 +62,20 @@ class _VolumeRender(torch.autograd.Function):
         acc = torch.empty((B,), dtype=torch.float32, device=dev)
         alpha = torch.empty((B, N), dtype=torch.float32, device=dev)
         w = torch.empty((B, N), dtype=torch.float32, device=dev)
+        lib = _lib.lib()
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().nerf_amd_volume_render(
-                _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(dirs), 3, _lib.ptr(rgb), _lib.ptr(disp),
-                _lib.ptr(alpha), _lib.ptr(acc), _lib.ptr(w), B, N, _lib.stream_ptr(dev)),
-                "nerf_amd_volume_render")
+            if from_rays:
+                _lib.check(lib.nerf_amd_volume_render_rays(
+                    _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(dirs), _lib.ptr(rgb), _lib.ptr(disp),
+                    _lib.ptr(alpha), _lib.ptr(acc), _lib.ptr(w), B, N, _lib.stream_ptr(dev)),
+                    "nerf_amd_volume_render_rays")
+            else:
+                _lib.check(lib.nerf_amd_volume_render(
+                    _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(dirs), 3, _lib.ptr(rgb), _lib.ptr(disp),
+                    _lib.ptr(alpha), _lib.ptr(acc), _lib.ptr(w), B, N, _lib.stream_ptr(dev)),
+                    "nerf_amd_volume_render")
         ctx.save_for_backward(raw, ts, dirs)
+        ctx.from_rays = from_rays
         return rgb, disp, alpha, acc, w
 
     @staticmethod
@@ -76,57 +88,47 @@ class _VolumeRender(torch.autograd.Function):
         def c(g):
             return None if g is None else g.contiguous().float()
         g_rgb, g_disp, g_alpha, g_acc, g_w = map(c, (g_rgb, g_disp, g_alpha, g_acc, g_w))
+        lib = _lib.lib()
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().nerf_amd_volume_render_backward(
-                _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(dirs), 3, _lib.ptr(g_rgb), _lib.ptr(g_disp),
-                _lib.ptr(g_alpha), _lib.ptr(g_acc), _lib.ptr(g_w), _lib.ptr(d_raw), B, N,
-                _lib.stream_ptr(dev)), "nerf_amd_volume_render_backward")
-        return d_raw, None, None
+            if ctx.from_rays:
+                _lib.check(lib.nerf_amd_volume_render_rays_backward(
+                    _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(dirs), _lib.ptr(g_rgb), _lib.ptr(g_disp),
+                    _lib.ptr(g_alpha), _lib.ptr(g_acc), _lib.ptr(g_w), _lib.ptr(d_raw), B, N,
+                    _lib.stream_ptr(dev)), "nerf_amd_volume_render_rays_backward")
+            else:
+                _lib.check(lib.nerf_amd_volume_render_backward(
+                    _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(dirs), 3, _lib.ptr(g_rgb), _lib.ptr(g_disp),
+                    _lib.ptr(g_alpha), _lib.ptr(g_acc), _lib.ptr(g_w), _lib.ptr(d_raw), B, N,
+                    _lib.stream_ptr(dev)), "nerf_amd_volume_render_backward")
+        return d_raw, None, None, None
 
 
 def volume_render_autograd(nerf_outs, ts, dirs):
     """volume_render (reference utils/rendering.py:47-85) with gradients to
     nerf_outs; ts and dirs get none (they carry none in the reference either)."""
-    return _VolumeRender.apply(nerf_outs.float(), ts.detach(), dirs.detach())
-
-
-# --------------------------------------------------------------------------
-# the dense layers under autograd (library GEMMs)
-# --------------------------------------------------------------------------
-def _dense_layers(net, x, d, precision):
-    """Data-flow of reference utils/nets.py:37-43 on already-encoded inputs,
-    through the module's own nn.Linear parameters so autograd reaches them."""
-    # 16-bit modes run the library GEMMs under bf16 autocast (fp16 would need loss scaling)
-    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(_lib.precision_code(precision) != _lib.F32)):
-        h = net.layers_0(x)
-        h = net.skip_conn_layer(torch.cat([h, x.to(h.dtype)], dim=1))
-        h = net.layers_1(h)
-        sigma = net.sigma_fc(h)
-        h = net.layers_2(h)
-        rgb = net.color_fc(torch.cat([h, d.to(h.dtype)], dim=1))
-        return torch.cat([rgb, sigma], dim=1).float()
-
-
-def nerf_forward_autograd(net, v, precision):
-    """Nerf.forward with gradients to the parameters: HIP encoder + library GEMMs."""
-    from .utils.xyz import positional_encoder
-    x, d = positional_encoder(v.detach(), net.Lp, net.Ld)
-    return _dense_layers(net, x, d, precision)
+    return _VolumeRender.apply(nerf_outs.float(), ts.detach(), dirs.detach(), False)
 
 
 # --------------------------------------------------------------------------
 # fused dense layers: HIP forward (saving activations) + HIP dX chain + HIP dW
 # --------------------------------------------------------------------------
+def _check_trainable(precision):
+    if _lib.precision_code(precision) == _lib.F32:
+        raise RuntimeError("fp32 training is not supported (NERF_AMD_EUNSUP): the training kernels are bf16; "
+                           "build the module with precision='bf16' (or 'fp16': bf16 training, fp16 inference)")
+
+
 class _FusedDense(torch.autograd.Function):
-    """(rays, jitter) -> raw [B,N,4], ts [B,N] through nerf_amd_mlp_forward_train;
-    backward: nerf_amd_mlp_backward for every layer's pre-activation gradient, then
-    nerf_amd_param_gradients (split-K GEMMs + column sums) into ONE flat fp32
-    vector in state_dict order, handed back to autograd as 24 views."""
+    """(rays, jitter) -> raw [B,N,4], ts [B,N]  -- or, with ``rays`` None, points v [P,6] -> raw [P,1,4] --
+    through nerf_amd_mlp_forward_train[_points]; backward: nerf_amd_mlp_backward for every layer's
+    pre-activation gradient, then nerf_amd_param_gradients (split-K GEMMs + column sums) into ONE flat
+    fp32 vector in state_dict order, handed back to autograd as 24 views."""
 
     @staticmethod
-    def forward(ctx, net, rays, jit, tbins, flags, seed, ray_id0, N, *params):
+    def forward(ctx, net, rays, jit, tbins, flags, seed, ray_id0, N, pts, *params):
         lib = _lib.lib()
-        B, dev = rays.size(0), rays.device
+        src = rays if rays is not None else pts
+        B, dev = src.size(0), src.device
         P = B * N
         packed = net.packed_weights(_lib.BF16)
         raw = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
@@ -136,14 +138,21 @@ class _FusedDense(torch.autograd.Function):
         posd = torch.empty((P, 32), dtype=torch.bfloat16, device=dev)
         with torch.cuda.device(dev):
             st = _lib.stream_ptr(dev)
-            _lib.check(lib.nerf_amd_mlp_forward_train(
-                _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(tbins), _lib.ptr(packed), flags, int(seed), int(ray_id0),
-                _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(acts), B, N, st), "nerf_amd_mlp_forward_train")
-            # encoder outputs in the reference's column order: the inputs of the dW products of
-            # layers_0.0 / skip_conn_layer / color_fc.0 (same sample positions: ts given)
-            _lib.check(lib.nerf_amd_sample_encode_bf16(
-                _lib.ptr(rays), _lib.ptr(ts), None, _lib.FLAG_TS_GIVEN, 0, 0,
-                _lib.ptr(posx), _lib.ptr(posd), None, B, N, st), "nerf_amd_sample_encode_bf16")
+            if rays is not None:
+                _lib.check(lib.nerf_amd_mlp_forward_train(
+                    _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(tbins), _lib.ptr(packed), flags, int(seed), int(ray_id0),
+                    _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(acts), B, N, st), "nerf_amd_mlp_forward_train")
+                # encoder outputs in the reference's column order: the inputs of the dW products of
+                # layers_0.0 / skip_conn_layer / color_fc.0 (same sample positions: ts given)
+                _lib.check(lib.nerf_amd_sample_encode_bf16(
+                    _lib.ptr(rays), _lib.ptr(ts), None, _lib.FLAG_TS_GIVEN, 0, 0,
+                    _lib.ptr(posx), _lib.ptr(posd), None, B, N, st), "nerf_amd_sample_encode_bf16")
+            else:
+                _lib.check(lib.nerf_amd_mlp_forward_train_points(
+                    _lib.ptr(pts), _lib.ptr(packed), _lib.ptr(raw), _lib.ptr(acts), P, st),
+                    "nerf_amd_mlp_forward_train_points")
+                _lib.check(lib.nerf_amd_encode_points_bf16(_lib.ptr(pts), _lib.ptr(posx), _lib.ptr(posd), P, st),
+                           "nerf_amd_encode_points_bf16")
         ctx.net, ctx.P = net, P
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.save_for_backward(acts, posx, posd)
@@ -175,36 +184,27 @@ class _FusedDense(torch.autograd.Function):
                 n *= s_
             grads.append(flat[off:off + n].view(shp))
             off += n
-        return (None,) * 8 + tuple(grads)
+        return (None,) * 9 + tuple(grads)
 
 
-def _fused_training_enabled(precision):
-    return _lib.precision_code(precision) != _lib.F32 and os.environ.get("NERF_AMD_TRAIN_FUSED", "1") != "0"
+def nerf_forward_autograd(net, v, precision):
+    """Nerf.forward (reference utils/nets.py:34-43) with gradients to the parameters: the fused
+    training forward on points, v [P,6] -> [P,4]."""
+    _check_trainable(precision)
+    params = [p for _, p in net.named_parameters()]
+    raw, _ = _FusedDense.apply(net, None, None, None, 0, 0, 0, 1, v.detach().contiguous(), *params)
+    return raw.reshape(-1, 4)
 
 
 def render_nerf_autograd(rays, net, N, tn, tf, jit, flags, precision, seed, ray_id0):
     """render_nerf (reference utils/rendering.py:13-45) with gradients to the
     parameters of ``net``; returns the same 5-tuple."""
     from .utils.rendering import _tbins
-    B, dev = rays.size(0), rays.device
-    if _fused_training_enabled(precision):
-        params = [p for _, p in net.named_parameters()]
-        raw, ts = _FusedDense.apply(net, rays, jit, _tbins(tn, tf, N, dev), flags, seed, ray_id0, N, *params)
-        dn = rays[:, 3:] / torch.norm(rays[:, 3:], dim=1, keepdim=True)
-        return _VolumeRender.apply(raw, ts, dn)
-    lib = _lib.lib()
-    P = B * N
-    posx = torch.empty((P, 63), dtype=torch.float32, device=dev)
-    posd = torch.empty((P, 27), dtype=torch.float32, device=dev)
-    ts = torch.empty((B, N), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(lib.nerf_amd_sample_encode(
-            _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)), flags, int(seed), int(ray_id0),
-            _lib.ptr(posx), _lib.ptr(posd), _lib.ptr(ts), B, N, _lib.stream_ptr(dev)),
-            "nerf_amd_sample_encode")
-    out = _dense_layers(net, posx, posd, precision).reshape(B, N, 4)
-    dn = rays[:, 3:] / torch.norm(rays[:, 3:], dim=1, keepdim=True)
-    return _VolumeRender.apply(out, ts, dn)
+    _check_trainable(precision)
+    dev = rays.device
+    params = [p for _, p in net.named_parameters()]
+    raw, ts = _FusedDense.apply(net, rays, jit, _tbins(tn, tf, N, dev), flags, seed, ray_id0, N, None, *params)
+    return _VolumeRender.apply(raw, ts, rays, True)
 
 
 # --------------------------------------------------------------------------
@@ -220,7 +220,9 @@ def train_step(net, optimizer, rays, gt, N, *, tn=2, tf=6, u=None, decay=1.0, gr
                precision=None, device_rng=False, seed=0, ray_id0=0):
     """zero_grad -> render_nerf -> MSELoss(rgb, gt) -> backward -> [grad all-reduce]
     -> optimizer.step -> lr *= decay.  Returns the (detached) loss.
-    Only ``rgb`` feeds the loss, as in the reference (train.py:52)."""
+    Only ``rgb`` feeds the loss, as in the reference (train.py:52).
+    The dense layers train in bf16 whatever the module's inference precision ('bf16' or 'fp16');
+    precision 'fp32' raises (no fp32 training kernels, no library fallback)."""
     from . import parallel
     from .utils.rendering import render_nerf
     optimizer.zero_grad(set_to_none=True)
@@ -239,21 +241,46 @@ def train_step(net, optimizer, rays, gt, N, *, tn=2, tf=6, u=None, decay=1.0, gr
 # --------------------------------------------------------------------------
 # the same step as ONE captured hipGraph (launch-bound at 4096-ray batches)
 # --------------------------------------------------------------------------
+class _HyperRing:
+    """Pinned host staging for the per-step Adam scalars.  The H2D copy of step k is asynchronous;
+    a single reused pinned buffer would be overwritten for step k+1 while step k's copy is still
+    queued on a GPU-bound stream (then Adam k runs with k+1's learning rate and bias corrections).
+    Each slot is reused only after the event recorded behind its own copy has completed."""
+
+    def __init__(self, slots=8):
+        self.bufs = [torch.zeros(6, dtype=torch.float32).pin_memory() for _ in range(slots)]
+        self.events = [None] * slots
+        self.k = 0
+
+    def push(self, values, dst):
+        i = self.k % len(self.bufs)
+        self.k += 1
+        if self.events[i] is not None:
+            self.events[i].synchronize()
+        h = self.bufs[i]
+        for j, v in enumerate(values):
+            h[j] = v
+        dst.copy_(h, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dst.device))
+        self.events[i] = ev
+
+
 class GraphedTrainStep:
     """``train_step`` (reference train.py:47-57) for the fused bf16 path with every buffer
     allocated once and the launches captured into hipGraphs that are replayed per iteration:
 
         graph A: forward (saving activations) -> encoder rows -> compositor -> MSE loss and its
                  gradient -> compositor backward -> dX chain -> all 24 parameter gradients
+                 (8 launches + one memset, all through the C ABI: no torch kernels)
         [one in-place all-reduce of the flat gradient vector when a process group is given]
-        graph B: Adam over the flat parameter vector -> re-pack the MFMA weight images
+        graph B: Adam over the flat parameter vector -> re-pack the two MFMA weight images
 
-    At 4096 rays x 64 samples the eager step spends a tenth of its time between 14 small
-    launches; the graph removes those gaps and the per-step Python / autograd bookkeeping.
     Step-dependent scalars do not live in kernel arguments: the jitter comes from the ``u``
     buffer (filled per call; default the reference's one ``torch.rand(B, N)`` draw from the CPU
-    generator, continued on the device by utils/host_rng.py), Adam's learning rate and bias corrections from a 6-float
-    device vector (nerf_amd_adam_step_hyper).  ``optimizer`` must be ``optim.FusedAdam``.
+    generator, continued on the device by utils/host_rng.py), Adam's learning rate and bias
+    corrections from a 6-float device vector (nerf_amd_adam_step_hyper) fed through a ring of
+    pinned buffers.  ``optimizer`` must be ``optim.FusedAdam``.
 
     ``step(rays, gt, u=None, decay=1.0)`` returns the loss as a 0-d device tensor (no sync).
     """
@@ -265,6 +292,7 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep needs optim.FusedAdam (one flat parameter vector)")
         if optimizer.net is not net:
             raise RuntimeError("the optimizer belongs to another module")
+        _check_trainable(net.precision)
         self.net, self.opt, self.group = net, optimizer, group
         self.B, self.N = int(n_rays), int(N)
         dev = optimizer.flat.device
@@ -283,12 +311,9 @@ class GraphedTrainStep:
         self.dys = torch.empty(nb, dtype=torch.uint8, device=dev)
         self.posx = torch.empty((P, 64), dtype=torch.bfloat16, device=dev)
         self.posd = torch.empty((P, 32), dtype=torch.bfloat16, device=dev)
-        self.dn = torch.empty((B, 3), **f32)
         self.rgb = torch.empty((B, 3), **f32)
         self.disp = torch.empty((B,), **f32)
         self.acc = torch.empty((B,), **f32)
-        self.alpha = torch.empty((B, N_), **f32)
-        self.w = torch.empty((B, N_), **f32)
         self.g_rgb = torch.empty((B, 3), **f32)
         self.d_raw = torch.empty((B, N_, 4), **f32)
         self.grads = torch.zeros(int(lib.nerf_amd_param_count()), **f32)
@@ -296,7 +321,7 @@ class GraphedTrainStep:
                                    device=dev)
         self.loss = torch.zeros((), **f32)
         self.hyper = torch.zeros(6, **f32)
-        self._hyper_host = torch.zeros(6, dtype=torch.float32).pin_memory()
+        self._ring = _HyperRing()
         # parameters' .grad are views of the flat gradient vector, as after the eager fused backward
         off = 0
         for p in optimizer.params:
@@ -318,16 +343,14 @@ class GraphedTrainStep:
         ck(lib.nerf_amd_sample_encode_bf16(ptr(self.rays), ptr(self.ts), None, _lib.FLAG_TS_GIVEN, 0, 0,
                                            ptr(self.posx), ptr(self.posd), None, B, N_, st),
            "nerf_amd_sample_encode_bf16")
-        torch.div(self.rays[:, 3:], torch.norm(self.rays[:, 3:], dim=1, keepdim=True), out=self.dn)
-        ck(lib.nerf_amd_volume_render(ptr(self.raw), ptr(self.ts), ptr(self.dn), 3, ptr(self.rgb), ptr(self.disp),
-                                      ptr(self.alpha), ptr(self.acc), ptr(self.w), B, N_, st),
-           "nerf_amd_volume_render")
-        diff = self.rgb - self.gt                                # MSELoss(rgb, gt) and its gradient
-        self.loss.copy_((diff * diff).mean())
-        torch.mul(diff, 2.0 / diff.numel(), out=self.g_rgb)
-        ck(lib.nerf_amd_volume_render_backward(ptr(self.raw), ptr(self.ts), ptr(self.dn), 3, ptr(self.g_rgb), None,
-                                               None, None, None, ptr(self.d_raw), B, N_, st),
-           "nerf_amd_volume_render_backward")
+        # only rgb feeds the loss (train.py:52): alpha / w are not materialised
+        ck(lib.nerf_amd_volume_render_rays(ptr(self.raw), ptr(self.ts), ptr(self.rays), ptr(self.rgb), ptr(self.disp),
+                                           None, ptr(self.acc), None, B, N_, st), "nerf_amd_volume_render_rays")
+        ck(lib.nerf_amd_mse_loss(ptr(self.rgb), ptr(self.gt), ptr(self.loss), ptr(self.g_rgb), B * 3, st),
+           "nerf_amd_mse_loss")
+        ck(lib.nerf_amd_volume_render_rays_backward(ptr(self.raw), ptr(self.ts), ptr(self.rays), ptr(self.g_rgb), None,
+                                                    None, None, None, ptr(self.d_raw), B, N_, st),
+           "nerf_amd_volume_render_rays_backward")
         ck(lib.nerf_amd_mlp_backward(ptr(self.d_raw), ptr(image), ptr(self.acts), ptr(self.dys), P, st),
            "nerf_amd_mlp_backward")
         ck(lib.nerf_amd_param_gradients(ptr(self.d_raw), ptr(self.acts), ptr(self.dys), ptr(self.posx),
@@ -344,11 +367,8 @@ class GraphedTrainStep:
     def _set_hyper(self, step):
         pg = self.opt.param_groups[0]
         b1, b2 = float(pg["betas"][0]), float(pg["betas"][1])
-        h = self._hyper_host
-        h[0], h[1], h[2], h[3] = float(pg["lr"]), b1, b2, float(pg["eps"])
-        h[4] = 1.0 - b1 ** step
-        h[5] = (1.0 - b2 ** step) ** 0.5
-        self.hyper.copy_(h, non_blocking=True)
+        self._ring.push((float(pg["lr"]), b1, b2, float(pg["eps"]), 1.0 - b1 ** step, (1.0 - b2 ** step) ** 0.5),
+                        self.hyper)
 
     def _capture(self):
         with torch.cuda.device(self.dev):
@@ -388,11 +408,7 @@ class GraphedTrainStep:
         self.opt.step_count += 1
         self._set_hyper(self.opt.step_count)
         self.graph_a.replay()
-        rank, world = parallel.world_info(self.group)
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.grads, op=dist.ReduceOp.SUM, group=self.group)
-            self.grads /= world
+        parallel.allreduce_flat_(self.grads, group=self.group)
         self.graph_b.replay()
         if decay != 1.0:
             for pg in self.opt.param_groups:

@@ -3,18 +3,16 @@
 Same constructor, same 24 state-dict keys and shapes (fp32 master weights,
 ``load_state_dict(..., strict=True)`` compatible with reference checkpoints,
 reference utils/nets.py:9-32, test.py:28), but ``forward`` runs the fused HIP
-kernel (encoding + 12 dense layers in one launch, csrc/mlp_bf16.hip /
+kernel (encoding + 12 dense layers in one launch, csrc/mlp_bf16_16.hip /
 csrc/mlp_f32.hip) on an MFMA-fragment-ordered copy of the weights.  That packed
 copy is a derived cache, rebuilt whenever a parameter changes.
 """
-import os
-
 import torch
 import torch.nn as nn
 
 from .. import _lib
 
-DEFAULT_PRECISION = os.environ.get("NERF_AMD_PRECISION", "bf16")
+DEFAULT_PRECISION = "bf16"
 
 
 class Nerf(nn.Module):
@@ -27,7 +25,9 @@ class Nerf(nn.Module):
     precision: 'bf16' (bf16 MFMA operands, fp32 accumulate; default),
                'fp16' (fp16 operands: same MFMA rate, 8x finer mantissa, values
                must stay below 65504) or 'fp32' (exact-f32 MFMA).  Keyword-only
-               superset of the reference signature.
+               superset of the reference signature.  It selects the INFERENCE kernel;
+               with gradients enabled 'bf16' and 'fp16' modules both run the bf16
+               training kernels (training.py) and 'fp32' raises (no fp32 training path).
     """
 
     def __init__(self, Lp=10, Ld=4, H=256, *, precision=None):

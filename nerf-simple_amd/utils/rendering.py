@@ -76,7 +76,7 @@ def volume_render(nerf_outs, ts, dirs, *, outputs=ALL_OUTPUTS):
 
 
 def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUTS,
-                precision=None, device_rng=False, seed=0, ray_id0=0, stage_events=None):
+                precision=None, device_rng=False, seed=0, ray_id0=0):
     """Stratified sampling along rays, NeRF query, compositing
     (reference utils/rendering.py:13-45).
 
@@ -85,9 +85,6 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
     net runs as given, sampling and compositing still run here).
     Returns (rgb [B,3], disp [B], alpha [B,N], acc [B], w [B,N]); alpha / w are
     None when left out of ``outputs``.
-    stage_events: optional list; when given, the two kernels of the fused path
-    are launched through their own C entry points and a (start, end)
-    torch.cuda.Event pair bracketing the MLP kernel is appended (bench.py).
     """
     _lib.require_cuda_f32(rays, "rays")
     if rays.dim() != 2 or rays.shape[1] != 6:
@@ -96,24 +93,29 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
     dev = rays.device
     rays = rays.detach().contiguous()
 
-    flags = 0
-    jit = None
-    pending_rng = None
+    fused = isinstance(net, Nerf) and net._fused_ok()
+    training = fused and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
+    # everything that can raise cheaply is checked BEFORE the jitter is drawn, so a failed call
+    # leaves torch's CPU generator untouched
+    for name, t_ in (("ts", ts), ("u", u)):
+        if t_ is not None and tuple(_lib.require_cuda_f32(t_, name).shape) != (B, N):
+            raise RuntimeError("u / ts must be [B, N]")
+    code, packed = None, None
+    if fused and not training:
+        code = _lib.precision_code(net.precision if precision is None else precision)
+        packed = net.packed_weights(code)
+
+    flags, jit, pending_rng = 0, None, None
     if ts is not None:
-        jit, flags = _lib.require_cuda_f32(ts, "ts").contiguous(), _lib.FLAG_TS_GIVEN
+        jit, flags = ts.contiguous(), _lib.FLAG_TS_GIVEN
     elif u is not None:
-        jit = _lib.require_cuda_f32(u, "u").contiguous()
+        jit = u.contiguous()
     elif device_rng:
         flags = _lib.FLAG_DEVICE_RNG
     else:
         # the reference's single CPU draw per call (:28-30): same numbers, same advance of torch's
         # CPU generator, produced on the device (host_rng.py)
         jit, pending_rng = reference_rand(B, N, dev)
-    if jit is not None and tuple(jit.shape) != (B, N):
-        raise RuntimeError("u / ts must be [B, N]")
-
-    fused = isinstance(net, Nerf) and net._fused_ok()
-    training = fused and torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters())
     if pending_rng is not None and (training or not fused):
         pending_rng.finish()                  # user / autograd code follows: the generator must be current
         pending_rng = None
@@ -125,40 +127,22 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
     if not fused:
         return _render_generic(rays, net, N, tn, tf, jit, flags, outputs, seed, ray_id0)
 
-    code = _lib.precision_code(net.precision if precision is None else precision)
-    packed = net.packed_weights(code)
-    lib = _lib.lib()
-    rgb = torch.empty((B, 3), dtype=torch.float32, device=dev)
-    disp = torch.empty((B,), dtype=torch.float32, device=dev)
-    acc = torch.empty((B,), dtype=torch.float32, device=dev)
-    alpha = torch.empty((B, N), dtype=torch.float32, device=dev) if "alpha" in outputs else None
-    w = torch.empty((B, N), dtype=torch.float32, device=dev) if "w" in outputs else None
-    ws = torch.empty(max(int(lib.nerf_amd_render_workspace_bytes(B, N)), 256), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        st = _lib.stream_ptr(dev)
-        if stage_events is None:
+    try:
+        lib = _lib.lib()
+        rgb = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        disp = torch.empty((B,), dtype=torch.float32, device=dev)
+        acc = torch.empty((B,), dtype=torch.float32, device=dev)
+        alpha = torch.empty((B, N), dtype=torch.float32, device=dev) if "alpha" in outputs else None
+        w = torch.empty((B, N), dtype=torch.float32, device=dev) if "w" in outputs else None
+        ws = torch.empty(max(int(lib.nerf_amd_render_workspace_bytes(B, N)), 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_render_forward(
                 _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)), _lib.ptr(packed), code,
                 flags, int(seed), int(ray_id0), _lib.ptr(rgb), _lib.ptr(disp), _lib.ptr(alpha),
-                _lib.ptr(acc), _lib.ptr(w), _lib.ptr(ws), B, N, st), "nerf_amd_render_forward")
-        else:
-            # the same two launches nerf_amd_render_forward makes, bracketed
-            raw = ws[:B * N * 16].view(torch.float32)
-            tsb = ws[(B * N * 16 + 255) // 256 * 256:][:B * N * 4].view(torch.float32)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _lib.check(lib.nerf_amd_mlp_forward_rays(
-                _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)), _lib.ptr(packed), code,
-                flags, int(seed), int(ray_id0), _lib.ptr(raw), _lib.ptr(tsb), B, N, st),
-                "nerf_amd_mlp_forward_rays")
-            e1.record()
-            stage_events.append((e0, e1))
-            dn = rays[:, 3:] / torch.norm(rays[:, 3:], dim=1, keepdim=True)
-            _lib.check(lib.nerf_amd_volume_render(
-                _lib.ptr(raw), _lib.ptr(tsb), _lib.ptr(dn.contiguous()), 3, _lib.ptr(rgb), _lib.ptr(disp),
-                _lib.ptr(alpha), _lib.ptr(acc), _lib.ptr(w), B, N, st), "nerf_amd_volume_render")
-    if pending_rng is not None:
-        pending_rng.finish()                  # the render is enqueued behind it: only the generator kernel is awaited
+                _lib.ptr(acc), _lib.ptr(w), _lib.ptr(ws), B, N, _lib.stream_ptr(dev)), "nerf_amd_render_forward")
+    finally:
+        if pending_rng is not None:
+            pending_rng.finish()              # the render is enqueued behind it: only the generator kernel is awaited
     return rgb, disp, alpha, acc, w
 
 

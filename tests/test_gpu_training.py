@@ -1,18 +1,23 @@
-"""GPU parity tests of the training step:
-loss, parameter gradients and the first Adam update for fixed (rays, u, gt,
-weights) against golden G6 (captured from the reference's own autograd), and the
-hand-written compositor backward against torch autograd of the CPU oracle.
+"""GPU parity tests of the training step: the hand-written bf16
+training kernels (fused forward saving activations, compositor forward / backward, dX chain, dW
+split-K GEMMs, Adam) against golden G6 (captured from the reference's own autograd) and against
+the CPU oracle's fp32 autograd on the same (rays, u, gt, weights).
 
-Tolerances: fp32 path -- same math, different GEMM blocking and a scan-ordered
-compositor; the first-layer gradients sum 4096 signed terms through 12 layers, so
-the bound is 3e-3 of each tensor's largest entry (observed 1e-3).  bf16 -- gradient direction only
-(cosine similarity), since 8-bit mantissas perturb small gradient entries."""
+Stated bounds (per parameter tensor, relative L2 = ||g_gpu - g_ref|| / ||g_ref||): bf16 operands
+and bf16-stored activations / activation gradients through 12 layers.
+  REL_L2_DEFAULT     nn.Linear-scale weights (the G6 set)
+  REL_L2_STRUCTURED  He-scale hidden weights with x8 head gains (the harsh set)
+The loss is computed from an fp32 compositor on bf16-MLP outputs: LOSS_RTOL."""
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-GRAD_RTOL = 3e-3
+# observed on MI355X (printed by the tests): default <= 1.1e-2, structured <= 9e-2 per tensor
+REL_L2_DEFAULT = 3e-2
+REL_L2_STRUCTURED = 2.5e-1
+REL_L2_ALL = {"default": 1.5e-2, "structured": 1e-1}      # all 595,844 gradient entries as one vector
+LOSS_RTOL = {"default": 2e-3, "structured": 2e-2}
 
 
 @pytest.fixture(scope="module")
@@ -59,56 +64,185 @@ def test_composite_backward_vs_autograd(dev, oracle):
     np.testing.assert_allclose(r_gpu.grad.cpu().numpy(), r_cpu.grad.numpy(), rtol=1e-3, atol=1e-6)
 
 
-def test_train_step_golden_fp32(dev, golden, synthetic):
-    """G6: 64 rays x 64 samples, MSELoss, Adam(lr=5e-4) -- reference train.py:51-55."""
+def rel_l2(got, want):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def _fused_grads(dev, synthetic, kind, rays, gt, u, N, precision="bf16"):
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.training import train_step
+    net = Nerf(precision=precision).to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, kind))
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    loss = train_step(net, opt, rays.to(dev), gt.to(dev), N, u=u.to(dev))
+    return float(loss), {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}
+
+
+def _compare_with_oracle(oracle, synthetic, kind, rays, gt, u, N, loss, grads, tag):
+    sd = synthetic.synthetic_state_dict(0, kind)
+    want_loss, want = oracle.train_step_grads(sd, rays, u, gt, N)
+    assert abs(loss - float(want_loss)) <= LOSS_RTOL[kind] * abs(float(want_loss)), (loss, float(want_loss))
+    bound = REL_L2_DEFAULT if kind == "default" else REL_L2_STRUCTURED
+    worst = {}
+    for k in want:
+        worst[k] = rel_l2(grads[k].numpy(), want[k].numpy())
+    print(f"{tag} {kind}: loss {loss:.6g} vs {float(want_loss):.6g}; rel L2 per tensor: max {max(worst.values()):.3e} "
+          f"({max(worst, key=worst.get)})")
+    for k, v in worst.items():
+        print(f"    {k:28s} {v:.3e}")
+    assert max(worst.values()) <= bound, worst
+    allg = torch.cat([grads[k].reshape(-1) for k in want]).numpy()
+    allw = torch.cat([want[k].reshape(-1) for k in want]).numpy()
+    assert rel_l2(allg, allw) <= REL_L2_ALL[kind]
+    return want
+
+
+def test_train_step_golden_fused(dev, golden, synthetic, oracle):
+    """G6 (64 rays x 64 samples, default weights, MSELoss, Adam(lr=5e-4): reference train.py:51-55)
+    through the FUSED bf16 kernels: loss, every gradient the fixture holds, gradient norms and the
+    first Adam update, under the stated bf16 bounds; then all 24 full gradients against the oracle."""
     from nerf_simple_amd.utils.nets import Nerf
     from nerf_simple_amd.training import train_step
     g = golden("train.npz")
-    net = Nerf(precision="fp32").to(dev)
+    rays, gt, u, N = t(g["rays"]), t(g["gt"]), t(g["u"]), int(g["N"])
+    net = Nerf(precision="bf16").to(dev)
     net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
     opt = torch.optim.Adam(net.parameters(), lr=5e-4)
-    loss = train_step(net, opt, t(g["rays"]).to(dev), t(g["gt"]).to(dev), int(g["N"]), u=t(g["u"]).to(dev))
-    assert abs(float(loss) - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    loss = float(train_step(net, opt, rays.to(dev), gt.to(dev), N, u=u.to(dev)))
+    assert abs(loss - float(g["loss"])) <= LOSS_RTOL["default"] * abs(float(g["loss"]))
     for k, p in net.named_parameters():
         grad = p.grad.cpu().numpy()
-        np.testing.assert_allclose(np.linalg.norm(grad), g[f"gnorm/{k}"], rtol=GRAD_RTOL, err_msg=k)
+        assert abs(np.linalg.norm(grad) / g[f"gnorm/{k}"] - 1) <= REL_L2_DEFAULT, k
         if f"grad/{k}" in g.files:
             want, got = g[f"grad/{k}"], grad
         else:
             want, got = g[f"gradc/{k}"], grad[:16, :16]
-        assert np.abs(got - want).max() <= GRAD_RTOL * max(np.abs(want).max(), 1e-12), k
+        assert rel_l2(got, want) <= 2 * REL_L2_DEFAULT, (k, rel_l2(got, want))     # 256-entry corners: fewer terms to average
         post = p.detach().cpu().numpy()
         wantp = g[f"post/{k}"] if f"post/{k}" in g.files else g[f"postc/{k}"]
         gotp = post if f"post/{k}" in g.files else post[:16, :16]
-        # first Adam step: update = lr * g / (|g| + eps), eps = 1e-8.  Where |g| is
-        # not small against eps the update is ~lr*sign(g) and must agree to fp32
-        # rounding; entries with |g| ~ eps amplify the (1e-3 relative) gradient
-        # difference and are only bounded by the step size.
-        solid = np.abs(want) > 1e-6
-        if solid.any():
-            assert np.abs(gotp - wantp)[solid].max() <= 1e-6, k
+        # first Adam step = lr * g / (|g| + eps): ~lr * sign(g) wherever |g| >> eps, so the update
+        # survives bf16 gradient noise except where the gradient changes sign
         assert np.abs(gotp - wantp).max() <= 2 * 5e-4, k
+        solid = np.abs(want) > max(0.2 * np.abs(want).max(), 1e-6)     # entries bf16 noise cannot flip
+        if solid.any():
+            assert np.abs(gotp - wantp)[solid].max() <= 1e-5, k
+    l2, grads = _fused_grads(dev, synthetic, "default", rays, gt, u, N)
+    assert l2 == loss                                            # same kernels, same inputs: reproducible
+    _compare_with_oracle(oracle, synthetic, "default", rays, gt, u, N, loss, grads, "G6")
+
+
+@pytest.mark.parametrize("kind", ["default", "structured"])
+@pytest.mark.parametrize("shape", [(576, 64), (577, 64), (37, 65)])
+def test_fused_training_vs_oracle(dev, synthetic, oracle, kind, shape):
+    """The fused training path against the CPU oracle's fp32 autograd (train.py:51-54) at a full-tile
+    size (576 x 64 = 144 tiles of 256 points) and at genuinely ragged ones: 577 x 64 (P % 256 = 64)
+    and 37 x 65 (P = 2405: P % 256 = 101, P % 32 = 5 -- partial tile, partial dW slab, partial mask
+    tile, out-of-range activation stores)."""
+    B, N = shape
+    gen = torch.Generator().manual_seed(B * 1000 + N)
+    pose = torch.from_numpy(oracle.spherical_to_pose(4, -30, 0)).float()
+    side = int(np.ceil(np.sqrt(B)))
+    rays = oracle.camera_rays(pose, [side, side, synthetic.focal_from_fov(side)])[:B].contiguous()
+    gt = torch.rand(B, 3, generator=gen)
+    u = torch.rand(B, N, generator=gen)
+    loss, grads = _fused_grads(dev, synthetic, kind, rays, gt, u, N)
+    _compare_with_oracle(oracle, synthetic, kind, rays, gt, u, N, loss, grads, f"{B}x{N}")
+
+
+def test_ragged_training_ignores_garbage_beyond_P(dev, synthetic, oracle):
+    """Same ragged case through the C ABI with the activation and dY buffers pre-filled with NaN:
+    nothing from points >= P (never written by the forward / dX kernels) may reach dW or db, and the
+    kernels are deterministic at a ragged size too."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.nets import Nerf
+    lib = _lib.lib()
+    B, N = 37, 65
+    P = B * N
+    pose = torch.from_numpy(oracle.spherical_to_pose(4, -30, 0)).float()
+    rays = oracle.camera_rays(pose, [7, 7, synthetic.focal_from_fov(7)])[:B].contiguous().to(dev)
+    u = torch.rand(B, N, generator=torch.Generator().manual_seed(1)).to(dev)
+    net = Nerf().to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+    packed, image = net.packed_weights(_lib.BF16), net.packed_weights(_lib.BF16_BWD)
+    tbins = torch.linspace(2, 6, N + 1).to(dev)
+    st = _lib.stream_ptr(dev)
+    nb = int(lib.nerf_amd_train_activation_bytes(P))
+    g = torch.randn(P, 4, generator=torch.Generator().manual_seed(5)).to(dev) * 1e-3
+    outs = []
+    for fill in (0xFF, 0x00, 0xFF):                     # 0xFFFF is a bf16 NaN
+        acts = torch.full((nb,), fill, dtype=torch.uint8, device=dev)
+        dys = torch.full((nb,), fill, dtype=torch.uint8, device=dev)
+        raw = torch.empty(B, N, 4, device=dev)
+        ts = torch.empty(B, N, device=dev)
+        posx = torch.empty(P, 64, dtype=torch.bfloat16, device=dev)
+        posd = torch.empty(P, 32, dtype=torch.bfloat16, device=dev)
+        scratch = torch.empty(int(lib.nerf_amd_param_gradients_scratch_bytes(P)), dtype=torch.uint8, device=dev)
+        flat = torch.empty(int(lib.nerf_amd_param_count()), device=dev)
+        ck = _lib.check
+        ck(lib.nerf_amd_mlp_forward_train(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tbins), _lib.ptr(packed), 0, 0, 0,
+                                          _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(acts), B, N, st), "forward_train")
+        ck(lib.nerf_amd_sample_encode_bf16(_lib.ptr(rays), _lib.ptr(ts), None, _lib.FLAG_TS_GIVEN, 0, 0, _lib.ptr(posx),
+                                           _lib.ptr(posd), None, B, N, st), "encode")
+        ck(lib.nerf_amd_mlp_backward(_lib.ptr(g), _lib.ptr(image), _lib.ptr(acts), _lib.ptr(dys), P, st), "backward")
+        ck(lib.nerf_amd_param_gradients(_lib.ptr(g), _lib.ptr(acts), _lib.ptr(dys), _lib.ptr(posx), _lib.ptr(posd),
+                                        _lib.ptr(scratch), _lib.ptr(flat), P, st), "param_gradients")
+        torch.cuda.synchronize()
+        outs.append((raw.clone(), flat.clone()))
+    for raw, flat in outs:
+        assert torch.isfinite(raw).all() and torch.isfinite(flat).all()
+        assert torch.equal(raw, outs[0][0])
+        assert float((flat - outs[0][1]).abs().max()) <= 1e-5 * float(outs[0][1].abs().max())
 
 
 def test_nerf_forward_autograd(dev, oracle, synthetic):
+    """Nerf.forward(v) with gradients (utils/nets.py:34-43 under autograd) = the fused training
+    forward in points mode + the HIP backward: outputs and all 24 gradients vs the oracle."""
     from nerf_simple_amd.utils.nets import Nerf
     sd = synthetic.synthetic_state_dict(0, "default")
-    v = synthetic.points_in_scene(96, seed=4)
+    v = synthetic.points_in_scene(300, seed=4)                    # 300 points: a ragged tile
     params = {k: p.clone().requires_grad_(True) for k, p in sd.items()}
-    oracle.nerf_forward(params, v).pow(2).sum().backward()
-    net = Nerf(precision="fp32").to(dev)
+    want_out = oracle.nerf_forward(params, v)
+    want_out.pow(2).sum().backward()
+    net = Nerf(precision="bf16").to(dev)
     net.load_state_dict(sd)
     out = net(v.to(dev))
-    assert out.requires_grad
+    assert out.requires_grad and out.shape == (300, 4)
+    with torch.no_grad():
+        assert torch.equal(out.detach(), net(v.to(dev)))          # the training forward computes what inference computes
     out.pow(2).sum().backward()
-    for k, p in net.named_parameters():
-        want = params[k].grad.numpy()
-        assert np.abs(p.grad.cpu().numpy() - want).max() <= GRAD_RTOL * np.abs(want).max(), k
+    worst = max(rel_l2(p.grad.cpu().numpy(), params[k].grad.numpy()) for k, p in net.named_parameters())
+    print("points-mode rel L2 max:", worst)
+    assert worst <= REL_L2_DEFAULT
+
+
+def test_training_precision_contract(dev, synthetic, golden):
+    """precision selects the inference kernel only: an 'fp16' module trains through the same bf16
+    kernels as a 'bf16' one (identical gradients), and 'fp32' training raises -- there is no fp32
+    training path and no library fallback."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.training import train_step
+    g = golden("train.npz")
+    rays, gt, u, N = t(g["rays"]), t(g["gt"]), t(g["u"]), int(g["N"])
+    la, ga = _fused_grads(dev, synthetic, "default", rays, gt, u, N, "bf16")
+    lb, gb = _fused_grads(dev, synthetic, "default", rays, gt, u, N, "fp16")
+    assert la == lb
+    for k in ga:       # dW accumulates with float atomics: equal to summation order
+        assert float((ga[k] - gb[k]).abs().max()) <= 1e-5 * max(float(ga[k].abs().max()), 1e-12), k
+    net = Nerf(precision="fp32").to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    with pytest.raises(RuntimeError, match="fp32 training is not supported"):
+        train_step(net, opt, rays.to(dev), gt.to(dev), N, u=u.to(dev))
+    with pytest.raises(RuntimeError, match="fp32 training is not supported"):
+        net(synthetic.points_in_scene(8, seed=1).to(dev))
+    with torch.no_grad():
+        assert net(synthetic.points_in_scene(8, seed=1).to(dev)).shape == (8, 4)      # fp32 inference is fine
 
 
 def test_bf16_training_reduces_loss(dev, synthetic, oracle):
-    """Config-5-shaped steps (bf16 GEMMs): gradient direction agrees with fp32 and
-    a few Adam steps reduce the loss against a fixed target."""
+    """Config-5-shaped steps: a few Adam steps reduce the loss against a fixed target."""
     from nerf_simple_amd.utils.nets import Nerf
     from nerf_simple_amd.training import train_step
     from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
@@ -117,64 +251,11 @@ def test_bf16_training_reduces_loss(dev, synthetic, oracle):
     rays = camera_rays([pose], [32, 32, synthetic.focal_from_fov(32)]).to(dev)
     gt = torch.rand(rays.shape[0], 3, generator=torch.Generator().manual_seed(2)).to(dev) * 0.2
     u = torch.rand(rays.shape[0], 64, generator=torch.Generator().manual_seed(3)).to(dev)
-    grads = {}
-    for prec in ("fp32", "bf16"):
-        net = Nerf(precision=prec).to(dev)
-        net.load_state_dict(sd)
-        opt = torch.optim.Adam(net.parameters(), lr=5e-4)
-        losses = [float(train_step(net, opt, rays, gt, 64, u=u)) for _ in range(1)]
-        grads[prec] = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu()
-        losses += [float(train_step(net, opt, rays, gt, 64, u=u)) for _ in range(8)]
-        assert losses[-1] < losses[0], (prec, losses)
-    cos = torch.nn.functional.cosine_similarity(grads["fp32"], grads["bf16"], dim=0)
-    print("cos(grad fp32, grad bf16) =", float(cos))
-    assert cos > 0.99
-
-
-def _grads_of(dev, synthetic, kind, precision, fused, rays, gt, u, N):
-    import os
-    from nerf_simple_amd.utils.nets import Nerf
-    from nerf_simple_amd.training import train_step
-    os.environ["NERF_AMD_TRAIN_FUSED"] = "1" if fused else "0"
-    try:
-        net = Nerf(precision=precision).to(dev)
-        net.load_state_dict(synthetic.synthetic_state_dict(0, kind))
-        opt = torch.optim.SGD(net.parameters(), lr=0.0)
-        loss = train_step(net, opt, rays, gt, N, u=u)
-        return float(loss), {k: p.grad.detach().float().cpu() for k, p in net.named_parameters()}
-    finally:
-        os.environ.pop("NERF_AMD_TRAIN_FUSED", None)
-
-
-@pytest.mark.parametrize("kind", ["default", "structured"])
-def test_fused_backward_matches_autograd(dev, synthetic, kind):
-    """The hand-written training path (fused forward saving activations, HIP dX chain,
-    HIP dW split-K kernel) against torch autograd over library GEMMs, tensor by tensor:
-    fp32 autograd is the reference; bf16 autograd shows what 8-bit mantissas cost."""
-    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
-    pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
-    rays = camera_rays([pose], [24, 24, synthetic.focal_from_fov(24)]).to(dev)       # 576 rays: a ragged tile
-    gt = torch.rand(rays.shape[0], 3, generator=torch.Generator().manual_seed(2)).to(dev)
-    N = 64
-    u = torch.rand(rays.shape[0], N, generator=torch.Generator().manual_seed(3)).to(dev)
-    l32, g32 = _grads_of(dev, synthetic, kind, "fp32", False, rays, gt, u, N)
-    l16, g16 = _grads_of(dev, synthetic, kind, "bf16", False, rays, gt, u, N)
-    lf, gf = _grads_of(dev, synthetic, kind, "bf16", True, rays, gt, u, N)
-    assert abs(lf - l32) <= 2e-2 * abs(l32) + 1e-6
-    worst, bad = 1.0, []
-    for k in g32:
-        a, b, c = g32[k].reshape(-1), gf[k].reshape(-1), g16[k].reshape(-1)
-        cos_f = float(torch.nn.functional.cosine_similarity(a, b, dim=0))
-        cos_a = float(torch.nn.functional.cosine_similarity(a, c, dim=0))
-        ratio = float(b.norm() / a.norm())
-        print(f"{kind} {k:28s} cos(fused,fp32)={cos_f:.5f} cos(autograd-bf16,fp32)={cos_a:.5f} |g| ratio={ratio:.4f}")
-        worst = min(worst, cos_f)
-        if not (cos_f >= 0.98 and 0.9 <= ratio <= 1.1):
-            bad.append(k)
-    assert not bad, bad
-    allf = torch.cat([gf[k].reshape(-1) for k in g32])
-    all32 = torch.cat([g32[k].reshape(-1) for k in g32])
-    assert float(torch.nn.functional.cosine_similarity(allf, all32, dim=0)) >= 0.995
+    net = Nerf(precision="bf16").to(dev)
+    net.load_state_dict(sd)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    losses = [float(train_step(net, opt, rays, gt, 64, u=u)) for _ in range(9)]
+    assert losses[-1] < losses[0], losses
 
 
 def test_training_forward_relu_mask_bits(dev, synthetic):
@@ -385,6 +466,37 @@ def test_graphed_train_step_matches_eager(dev, golden, synthetic):
     assert float((qa - qb).abs().max()) <= 2e-2 * max(1.0, float(qa.abs().max()))
 
 
+def test_graphed_train_step_without_host_sync(dev, golden, synthetic):
+    """Six graphed steps with explicit u, a decaying learning rate and NO host sync in between (the
+    config-5 loop): the Adam scalars of step k must not be overwritten by step k+1's while step k is
+    still queued.  A long GPU-side delay in front of the first step makes the host run far ahead."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.optim import FusedAdam
+    from nerf_simple_amd.training import lr_decay_factor, GraphedTrainStep
+    g = golden("train.npz")
+    rays, gt, N = t(g["rays"]).to(dev), t(g["gt"]).to(dev), int(g["N"])
+    decay = lr_decay_factor(5e-4, 1e-4, 6)
+    us = [torch.rand(rays.shape[0], N, generator=torch.Generator().manual_seed(200 + i)).to(dev) for i in range(6)]
+    finals = []
+    for synced in (True, False):
+        net = Nerf(precision="bf16").to(dev)
+        net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+        opt = FusedAdam(net, lr=5e-4)
+        stepper = GraphedTrainStep(net, opt, rays.shape[0], N)
+        torch.cuda.synchronize()
+        if not synced:
+            torch.cuda._sleep(int(2e9))                      # ~1 s of GPU time queued ahead of the steps
+        for i in range(6):
+            stepper.step(rays, gt, u=us[i], decay=decay)
+            if synced:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        finals.append(opt.flat.clone().cpu())
+    d = (finals[0] - finals[1]).abs()
+    # identical schedules: only the dW atomics' summation order differs between the runs
+    assert float(d.max()) <= 6 * 5e-4 and float(d.mean()) <= 1e-5 and float((d > 1e-5).float().mean()) <= 0.06
+
+
 def test_fused_adam_matches_torch(dev, golden, synthetic):
     """N3: optim.FusedAdam == torch.optim.Adam (reference train.py:43,55-57) -- on golden G6 for the
     first step, and over several decayed steps of the fused bf16 path against torch's optimizer."""
@@ -392,7 +504,7 @@ def test_fused_adam_matches_torch(dev, golden, synthetic):
     from nerf_simple_amd.optim import FusedAdam
     from nerf_simple_amd.training import train_step, lr_decay_factor
     g = golden("train.npz")
-    net = Nerf(precision="fp32").to(dev)
+    net = Nerf(precision="bf16").to(dev)
     net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
     opt = FusedAdam(net, lr=5e-4)
     train_step(net, opt, t(g["rays"]).to(dev), t(g["gt"]).to(dev), int(g["N"]), u=t(g["u"]).to(dev))
@@ -401,9 +513,9 @@ def test_fused_adam_matches_torch(dev, golden, synthetic):
         wantp = g[f"post/{k}"] if f"post/{k}" in g.files else g[f"postc/{k}"]
         post = p.detach().cpu().numpy()
         gotp = post if f"post/{k}" in g.files else post[:16, :16]
-        solid = np.abs(want_g) > 1e-6
+        solid = np.abs(want_g) > max(0.2 * np.abs(want_g).max(), 1e-6)     # entries bf16 noise cannot flip
         if solid.any():
-            assert np.abs(gotp - wantp)[solid].max() <= 1e-6, k
+            assert np.abs(gotp - wantp)[solid].max() <= 1e-5, k
         assert np.abs(gotp - wantp).max() <= 1e-3, k
 
     # the update rule itself, free of the dW atomics' run-to-run summation order: both optimizers

@@ -40,7 +40,7 @@ def test_header_symbols_exported(lib):
 def test_introspection(lib):
     assert lib.nerf_amd_abi_version() == 1
     assert lib.nerf_amd_param_count() == 595844
-    assert lib.nerf_amd_packed_bytes(1) == 1202 * 1024 + 1172 * 1024 + 2464 * 4
+    assert lib.nerf_amd_packed_bytes(1) == lib.nerf_amd_packed_bytes(2) == 1172 * 1024 + 2464 * 4
     assert lib.nerf_amd_packed_bytes(0) == 2360 * 1024 + 154 * 16 * 4
     assert lib.nerf_amd_packed_bytes(7) < 0
     assert lib.nerf_amd_render_workspace_bytes(16000, 128) >= 16000 * 128 * 20
@@ -53,20 +53,22 @@ def test_layout_selfcheck(lib):
 
 def test_layout_maps(lib):
     """Spot-check the k-permutations against their definitions (csrc/nerf_layout.h)."""
-    # bf16 chain order: element j of lane half h in k-step s is feature
-    # 16s + 8(j>>2) + 4h + (j&3)  (accumulator row order of mfma 32x32x16)
-    for s in range(16):
-        for h in range(2):
-            for j in range(8):
-                assert lib.nerf_amd_layout_src_col(1, 1, s, h, j) == 16 * s + 8 * (j >> 2) + 4 * h + (j & 3)
+    # 16-bit chain order (bf16 and fp16 share it): element j of lane group g in k-step q is feature
+    # 32q + 16(j>>2) + 4g + (j&3)  (rows of two stacked 16-row accumulator tiles of mfma 16x16x32)
+    for prec in (1, 2):
+        for q in range(8):
+            for g in range(4):
+                for j in range(8):
+                    assert lib.nerf_amd_layout_src_col(prec, 1, q, g, j) == 32 * q + 16 * (j >> 2) + 4 * g + (j & 3)
     # skip layer: chain part then posx slots offset by 256 ([h ; x], h first)
-    cols = sorted(lib.nerf_amd_layout_src_col(1, 5, s, h, j)
-                  for s in range(16, 20) for h in range(2) for j in range(8))
+    cols = sorted(lib.nerf_amd_layout_src_col(1, 5, s, g, j)
+                  for s in range(8, 10) for g in range(4) for j in range(8))
     assert cols == [-1] + list(range(256, 319))
     # layer 0 covers the 63 posx columns exactly once
-    cols = sorted(lib.nerf_amd_layout_src_col(1, 0, s, h, j)
-                  for s in range(4) for h in range(2) for j in range(8))
+    cols = sorted(lib.nerf_amd_layout_src_col(1, 0, s, g, j)
+                  for s in range(2) for g in range(4) for j in range(8))
     assert cols == [-1] + list(range(63))
+    assert lib.nerf_amd_layout_src_col(1, 1, 8, 0, 0) == -2 and lib.nerf_amd_layout_src_col(1, 1, 0, 4, 0) == -2
     # f32 chain order: register i of tile t in lane group g is feature 16t + 4g + i
     for s in range(64):
         for g in range(4):
