@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 1
+#define NERF_AMD_ABI_VERSION 2
 
 /* error codes */
 #define NERF_AMD_EINVAL   (-1)   /* bad argument (null pointer, negative size, ...) */
@@ -50,8 +50,11 @@ int      nerf_amd_abi_version(void);
 int64_t  nerf_amd_param_count(void);
 /* bytes of the packed weight image for a precision (the caller allocates it) */
 int64_t  nerf_amd_packed_bytes(int precision);
-/* bytes of workspace nerf_amd_render_forward needs for B rays x N samples */
-int64_t  nerf_amd_render_workspace_bytes(int64_t B, int N);
+/* bytes of workspace nerf_amd_render_forward / _pixels_forward need for B rays x N samples.
+ * 0 for the 16-bit precisions up to 768 samples per ray: those run as ONE launch (sampling +
+ * encoding + MLP + compositing, samples composited out of LDS) and `workspace` may be NULL;
+ * otherwise raw[B,N,4] + ts[B,N] of the two-launch path. */
+int64_t  nerf_amd_render_workspace_bytes(int precision, int64_t B, int N);
 /* host-side self-check of the packed-weight index math (bijectivity of the
  * k-permutations, offsets, sizes); 0 = consistent.  Used by the CPU tests. */
 int      nerf_amd_layout_selfcheck(void);
@@ -129,12 +132,19 @@ int nerf_amd_volume_render_rays_backward(const float* raw, const float* ts, cons
  *   tbins    linspace(tn, tf, N+1) computed by the caller [N+1] (device), so
  *            bin edges are bit-identical to torch.linspace (utils/rendering.py:25)
  *   alpha,w  optional (NULL to skip the 8 B/sample of output traffic)
- *   workspace  nerf_amd_render_workspace_bytes(B,N) bytes, 256-B aligned       */
+ *   workspace  nerf_amd_render_workspace_bytes(precision,B,N) bytes, 256-B aligned (NULL if 0) */
 int nerf_amd_render_forward(const float* rays, const float* u, const float* tbins,
                             const void* packed, int precision, uint32_t flags,
                             uint64_t seed, int64_t ray_id0,
                             float* rgb, float* disp, float* alpha, float* acc, float* w,
                             void* workspace, int64_t B, int N, void* stream);
+
+/* Image-driver form (the body of utils/rendering.py:102-105 for one batch): the same render, output
+ * pixels[B,4] = [clip(rgb,0,1), disparity]; rgb is clipped AFTER compositing, disparity is not. */
+int nerf_amd_render_pixels_forward(const float* rays, const float* u, const float* tbins,
+                                   const void* packed, int precision, uint32_t flags,
+                                   uint64_t seed, int64_t ray_id0,
+                                   float* pixels, void* workspace, int64_t B, int N, void* stream);
 
 /* Stage 1 of the above on its own (sampling + encoding + MLP): writes
  * raw[B,N,4] and ts[B,N].  Exposed for the importance-sampling caller, which
@@ -150,11 +160,11 @@ int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tb
  * p = ray0 + i = h*W + w.  h_pose: HOST pointer to a row-major 3x4 / 4x4 pose. */
 int nerf_amd_generate_rays(const float* h_pose, int H, int W, float f,
                            int64_t ray0, int64_t n_rays, float* rays, void* stream);
-int64_t nerf_amd_render_image_workspace_bytes(int64_t n_rays, int N);
+int64_t nerf_amd_render_image_workspace_bytes(int precision, int64_t n_rays, int N);
 /* One call = the body of the reference's per-image loop (utils/rendering.py:139-151)
  * for pixels [ray0, ray0+n_rays) of an HxW view: ray generation, render_nerf,
  * clip(rgb,0,1) after compositing, disparity un-clipped ->
- * pixels[n_rays,4] = [r,g,b,disparity].  Three launches, no host sync; the
+ * pixels[n_rays,4] = [r,g,b,disparity].  Two launches (three on the two-launch path), no host sync; the
  * multi-GPU driver calls it per rank and all-gathers `pixels`.  u / tbins /
  * flags / seed as in nerf_amd_render_forward (u indexed from ray0). */
 int nerf_amd_render_image_forward(const float* h_pose, int H, int W, float f,

@@ -35,7 +35,7 @@ _SIGNATURES = {
     "nerf_amd_abi_version": (_i32, []),
     "nerf_amd_param_count": (_i64, []),
     "nerf_amd_packed_bytes": (_i64, [_i32]),
-    "nerf_amd_render_workspace_bytes": (_i64, [_i64, _i32]),
+    "nerf_amd_render_workspace_bytes": (_i64, [_i32, _i64, _i32]),
     "nerf_amd_layout_selfcheck": (_i32, []),
     "nerf_amd_layout_src_col": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "nerf_amd_pack_weights": (_i32, [_vp, _vp, _i32, _vp]),
@@ -52,7 +52,7 @@ _SIGNATURES = {
     "nerf_amd_encode_points_bf16": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "nerf_amd_sample_encode": (_i32, [_vp, _vp, _vp, _u32, _u64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_generate_rays": (_i32, [_vp, _i32, _i32, ctypes.c_float, _i64, _i64, _vp, _vp]),
-    "nerf_amd_render_image_workspace_bytes": (_i64, [_i64, _i32]),
+    "nerf_amd_render_image_workspace_bytes": (_i64, [_i32, _i64, _i32]),
     "nerf_amd_render_image_forward": (_i32, [_vp, _i32, _i32, ctypes.c_float, _i64, _i64, _vp, _vp, _vp, _i32,
                                              _u32, _u64, _vp, _vp, _i32, _vp]),
     "nerf_amd_sample_pdf": (_i32, [_vp, _vp, _vp, _u32, _u64, _i64, _vp, _i64, _i32, _i32, _vp]),
@@ -70,6 +70,8 @@ _SIGNATURES = {
     "nerf_amd_adam_step_hyper": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "nerf_amd_render_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _u32, _u64, _i64,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_render_pixels_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _u32, _u64, _i64,
+                                              _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_mlp_forward_rays": (_i32, [_vp, _vp, _vp, _vp, _i32, _u32, _u64, _i64,
                                          _vp, _vp, _i64, _i32, _vp]),
 }
@@ -97,7 +99,7 @@ def lib():
                 for name, (res, args) in _SIGNATURES.items():
                     fn = getattr(h, name)          # AttributeError if an export is missing
                     fn.restype, fn.argtypes = res, args
-                if h.nerf_amd_abi_version() != 1:
+                if h.nerf_amd_abi_version() != 2:
                     raise RuntimeError("libnerf_amd.so ABI version mismatch")
                 _lib = h
     return _lib

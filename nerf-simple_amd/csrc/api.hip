@@ -42,6 +42,11 @@ inline bool bad_precision(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF1
 inline bool bad_image(int p) { return bad_precision(p) && p != NERF_AMD_BF16_BWD; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+// the fused render kernel (sampling + MLP + compositing in one launch) serves the 16-bit precisions up
+// to FUSED_RENDER_MAX_N samples per ray
+inline bool fused_render(int precision, int N) {
+    return (precision == NERF_AMD_BF16 || precision == NERF_AMD_FP16) && N <= FUSED_RENDER_MAX_N;
+}
 int launch_mlp(const MlpArgs& a, int rays_mode, int precision, hipStream_t s) {
     if (precision == NERF_AMD_F32) return nerf_amd_launch_mlp_f32(&a, rays_mode, s);
     if (precision == NERF_AMD_FP16) return nerf_amd_launch_mlp_f16_16(&a, rays_mode, s);
@@ -60,14 +65,16 @@ int64_t nerf_amd_packed_bytes(int precision) {
     return precision == NERF_AMD_F32 ? F32_PACKED_BYTES : B16_IMAGE_BYTES;
 }
 
-int64_t nerf_amd_render_image_workspace_bytes(int64_t n_rays, int N) {
-    if (n_rays < 0 || N <= 0) return NERF_AMD_EINVAL;
-    // rays[n,6] + raw[n,N,4] + ts[n,N]
+int64_t nerf_amd_render_image_workspace_bytes(int precision, int64_t n_rays, int N) {
+    if (n_rays < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
+    // rays[n,6] (+ raw[n,N,4] + ts[n,N] on the two-launch path)
+    if (fused_render(precision, N)) return align_up(n_rays * 24, 256);
     return align_up(n_rays * 24, 256) + align_up(n_rays * N * 16, 256) + align_up(n_rays * N * 4, 256);
 }
 
-int64_t nerf_amd_render_workspace_bytes(int64_t B, int N) {
-    if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
+int64_t nerf_amd_render_workspace_bytes(int precision, int64_t B, int N) {
+    if (B < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
+    if (fused_render(precision, N)) return 0;
     // raw[B,N,4] + ts[B,N]
     return align_up(B * N * 16, 256) + align_up(B * N * 4, 256);
 }
@@ -238,7 +245,18 @@ int nerf_amd_render_forward(const float* rays, const float* u, const float* tbin
                             int N, void* stream) {
     if (B < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
     if (B == 0) return 0;
-    if (!workspace || !rgb || !disp || !acc) return NERF_AMD_EINVAL;
+    if (!rgb || !disp || !acc) return NERF_AMD_EINVAL;
+    if (fused_render(precision, N)) {
+        if (!rays || !packed) return NERF_AMD_EINVAL;
+        if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
+        if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+        MlpArgs a{};
+        a.rays = rays; a.u = u; a.tbins = tbins; a.packed = packed;
+        a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
+        a.rgb = rgb; a.disp = disp; a.alpha = alpha; a.acc = acc; a.w = w;
+        return launch_mlp(a, 1, precision, S(stream));
+    }
+    if (!workspace) return NERF_AMD_EINVAL;
     float* raw = reinterpret_cast<float*>(workspace);
     float* ts = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up(B * N * 16, 256));
     int rc = nerf_amd_mlp_forward_rays(rays, u, tbins, packed, precision, flags, seed, ray_id0, raw, ts, B, N,
@@ -246,6 +264,32 @@ int nerf_amd_render_forward(const float* rays, const float* u, const float* tbin
     if (rc) return rc;
     // dirs = rays[:,3:] normalised inside the kernel (utils/rendering.py:37,43)
     return nerf_amd_launch_composite(raw, ts, rays + 3, 6, rgb, disp, alpha, acc, w, B, N, 1, nullptr, S(stream));
+}
+
+int nerf_amd_render_pixels_forward(const float* rays, const float* u, const float* tbins, const void* packed,
+                                   int precision, uint32_t flags, uint64_t seed, int64_t ray_id0, float* pixels,
+                                   void* workspace, int64_t B, int N, void* stream) {
+    if (B < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (!pixels) return NERF_AMD_EINVAL;
+    if (fused_render(precision, N)) {
+        if (!rays || !packed) return NERF_AMD_EINVAL;
+        if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
+        if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+        MlpArgs a{};
+        a.rays = rays; a.u = u; a.tbins = tbins; a.packed = packed;
+        a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
+        a.pixels = pixels;
+        return launch_mlp(a, 1, precision, S(stream));
+    }
+    if (!workspace) return NERF_AMD_EINVAL;
+    float* raw = reinterpret_cast<float*>(workspace);
+    float* ts = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + align_up(B * N * 16, 256));
+    int rc = nerf_amd_mlp_forward_rays(rays, u, tbins, packed, precision, flags, seed, ray_id0, raw, ts, B, N,
+                                       stream);
+    if (rc) return rc;
+    return nerf_amd_launch_composite(raw, ts, rays + 3, 6, nullptr, nullptr, nullptr, nullptr, nullptr, B, N, 1,
+                                     pixels, S(stream));
 }
 
 int nerf_amd_generate_rays(const float* h_pose, int H, int W, float f, int64_t ray0, int64_t n_rays,
@@ -266,15 +310,11 @@ int nerf_amd_render_image_forward(const float* h_pose, int H, int W, float f, in
     if (!workspace || !pixels || !packed) return NERF_AMD_EINVAL;
     char* ws = reinterpret_cast<char*>(workspace);
     float* rays = reinterpret_cast<float*>(ws);
-    float* raw = reinterpret_cast<float*>(ws + align_up(n_rays * 24, 256));
-    float* ts = reinterpret_cast<float*>(ws + align_up(n_rays * 24, 256) + align_up(n_rays * N * 16, 256));
     int rc = nerf_amd_generate_rays(h_pose, H, W, f, ray0, n_rays, rays, stream);
     if (rc) return rc;
     // jitter is keyed by the GLOBAL pixel id, so the image does not depend on how it is sharded
-    rc = nerf_amd_mlp_forward_rays(rays, u, tbins, packed, precision, flags, seed, ray0, raw, ts, n_rays, N, stream);
-    if (rc) return rc;
-    return nerf_amd_launch_composite(raw, ts, rays + 3, 6, nullptr, nullptr, nullptr, nullptr, nullptr, n_rays, N,
-                                     1, pixels, S(stream));
+    return nerf_amd_render_pixels_forward(rays, u, tbins, packed, precision, flags, seed, ray0, pixels,
+                                          ws + align_up(n_rays * 24, 256), n_rays, N, stream);
 }
 
 int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u, uint32_t flags, uint64_t seed,

@@ -13,17 +13,20 @@
 // 20 B read per sample (+8 B written when alpha / w are requested) and 20 B written per ray.
 // Not HBM-bound in practice: the exact-fp32 softplus / exp (ocml expf, log1pf) and the two scans
 // cost ~400 VALU instructions per 64 samples, which is what sets its 3.4 TB/s.
-#include "nerf_device.h"
+#include "composite_device.h"
 
 namespace {
 
+using nerf_composite::wave_sum;
+
 constexpr int RAYS_PER_BLOCK = 4;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
+struct GlobalSamples {                        // the ray's samples in HBM
+    const float* rts;
+    const f32x4* rraw;
+    __device__ __forceinline__ float t(int i) const { return rts[i]; }
+    __device__ __forceinline__ f32x4 c(int i) const { return rraw[i]; }
+};
 
 __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_kernel(
     const float* __restrict__ raw, const float* __restrict__ ts, const float* __restrict__ dirs,
@@ -33,74 +36,10 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_kernel(
     const long long ray = (long long)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= B) return;                      // whole wave leaves together; no barriers below
     const int lane = threadIdx.x & 63;
-
     const float* d = dirs + ray * dirs_stride;
-    float d0 = d[0], d1 = d[1], d2 = d[2];
-    if (normalize_dirs) {       // render path: dirs = rays[:,3:] / ||rays[:,3:]||  (utils/rendering.py:37)
-        const float n = norm3(d0, d1, d2);
-        d0 = __fdiv_rn(d0, n); d1 = __fdiv_rn(d1, n); d2 = __fdiv_rn(d2, n);
-    }
-    const float dnorm = norm3(d0, d1, d2);                 // torch.norm(dirs[..., None, :], dim=-1)
-
-    const float* rts = ts + ray * N;
-    const f32x4* rraw = reinterpret_cast<const f32x4*>(raw) + ray * N;
-    float carry = 1.0f;                        // transmittance entering this chunk
-    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
-
-    for (int base = 0; base < N; base += 64) {
-        const int i = base + lane;
-        const bool valid = i < N;
-        float a = 0.f, t = 0.f, fac = 1.0f;
-        f32x4 c = {0.f, 0.f, 0.f, 0.f};
-        if (valid) {
-            t = rts[i];
-            c = rraw[i];
-            float delta = (i == N - 1) ? 1e10f : __fsub_rn(rts[i + 1], t);
-            delta = __fmul_rn(delta, dnorm);
-            const float sigma = c[3];
-            const float sp = sigma > 20.f ? sigma : log1pf(expf(sigma));
-            a = __fsub_rn(1.0f, expf(__fmul_rn(-sp, delta)));
-            fac = __fadd_rn(__fsub_rn(1.0f, a), 1e-10f);
-        }
-        // inclusive product scan across the wave
-        float incl = fac;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float up = __shfl_up(incl, off);
-            if (lane >= off) incl *= up;
-        }
-        float excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.0f;
-        const float T = carry * excl;
-        const float wt = a * T;
-        carry *= __shfl(incl, 63);
-        if (valid) {
-            if (alpha) alpha[ray * N + i] = a;
-            if (w) w[ray * N + i] = wt;
-            sr += wt * c[0];
-            sg += wt * c[1];
-            sb += wt * c[2];
-            sd += wt * t;
-            sa += wt;
-        }
-    }
-    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb);
-    sd = wave_sum(sd); sa = wave_sum(sa);
-    if (lane == 0) {
-        const float q = __fdiv_rn(sd, sa);
-        const float m = (q != q) ? q : fmaxf(1e-10f, q);   // torch.max propagates NaN
-        const float dsp = __fdiv_rn(1.0f, m);
-        if (rgb) { rgb[ray * 3 + 0] = sr; rgb[ray * 3 + 1] = sg; rgb[ray * 3 + 2] = sb; }
-        if (acc) acc[ray] = sa;
-        if (disp) disp[ray] = dsp;
-        if (pixels) {
-            // image-driver epilogue (utils/rendering.py:103-105): clip rgb to [0,1]
-            // AFTER compositing (torch.clip passes NaN through), disparity un-clipped
-            auto clip01 = [](float v) { return (v != v) ? v : fminf(fmaxf(v, 0.f), 1.f); };
-            const f32x4 px = {clip01(sr), clip01(sg), clip01(sb), dsp};
-            *reinterpret_cast<f32x4*>(pixels + ray * 4) = px;
-        }
-    }
+    const float dnorm = nerf_composite::unit_dir_norm(d[0], d[1], d[2], normalize_dirs != 0);
+    const GlobalSamples src{ts + ray * N, reinterpret_cast<const f32x4*>(raw) + ray * N};
+    nerf_composite::composite_ray(src, N, lane, dnorm, ray, nerf_composite::RayOut{rgb, disp, alpha, acc, w, pixels});
 }
 
 // ---- backward ---------------------------------------------------------------

@@ -1,0 +1,98 @@
+// composite_device.h -- the per-ray compositing routine (reference utils/rendering.py:47-85), shared
+// by composite.hip (samples read from HBM) and the fused render kernel in mlp_bf16_16.hip (samples
+// read from the workgroup's LDS ring).  ONE wavefront per ray, one sample per lane, N walked in
+// chunks of 64 with the transmittance carried between chunks.  Every floating-point operation is
+// written as one explicitly rounded op (no contraction left to the compiler), so both callers
+// produce bit-identical results from bit-identical samples.
+#pragma once
+#include "nerf_device.h"
+
+namespace nerf_composite {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off));
+    return v;
+}
+
+// ||d / ||d|| || as the reference computes it: dirs = rays[:,3:] / norm (rendering.py:37), then
+// torch.norm(dirs[..., None, :], dim=-1) inside volume_render (:62)
+__device__ __forceinline__ float unit_dir_norm(float d0, float d1, float d2, bool normalize) {
+    if (normalize) {
+        const float n = norm3(d0, d1, d2);
+        d0 = __fdiv_rn(d0, n); d1 = __fdiv_rn(d1, n); d2 = __fdiv_rn(d2, n);
+    }
+    return norm3(d0, d1, d2);
+}
+
+struct RayOut {            // any pointer may be NULL
+    float* rgb;            // [B,3]
+    float* disp;           // [B]
+    float* alpha;          // [B,N]
+    float* acc;            // [B]
+    float* w;              // [B,N]
+    float* pixels;         // [B,4] = [clip(rgb,0,1), disparity]  (image drivers, rendering.py:103-105)
+};
+
+// Src: float t(int i) const; f32x4 c(int i) const;  -- sample i of THIS ray (0 <= i < N)
+template <class Src>
+__device__ __forceinline__ void composite_ray(const Src& src, int N, int lane, float dnorm, long long ray,
+                                              const RayOut& o) {
+    float carry = 1.0f;                        // transmittance entering this chunk
+    float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    for (int base = 0; base < N; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < N;
+        float a = 0.f, t = 0.f, fac = 1.0f;
+        f32x4 c = {0.f, 0.f, 0.f, 0.f};
+        if (valid) {
+            t = src.t(i);
+            c = src.c(i);
+            float delta = (i == N - 1) ? 1e10f : __fsub_rn(src.t(i + 1), t);
+            delta = __fmul_rn(delta, dnorm);
+            const float sigma = c[3];
+            const float sp = sigma > 20.f ? sigma : log1pf(expf(sigma));      // softplus(beta=1, threshold=20)
+            a = __fsub_rn(1.0f, expf(__fmul_rn(-sp, delta)));
+            fac = __fadd_rn(__fsub_rn(1.0f, a), 1e-10f);
+        }
+        // inclusive product scan across the wave, shifted by one lane = exclusive cumprod (rendering.py:68)
+        float incl = fac;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const float up = __shfl_up(incl, off);
+            if (lane >= off) incl = __fmul_rn(incl, up);
+        }
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0f;
+        const float T = __fmul_rn(carry, excl);
+        const float wt = __fmul_rn(a, T);
+        carry = __fmul_rn(carry, __shfl(incl, 63));
+        if (valid) {
+            if (o.alpha) o.alpha[ray * N + i] = a;
+            if (o.w) o.w[ray * N + i] = wt;
+            sr = __fmaf_rn(wt, c[0], sr);
+            sg = __fmaf_rn(wt, c[1], sg);
+            sb = __fmaf_rn(wt, c[2], sb);
+            sd = __fmaf_rn(wt, t, sd);
+            sa = __fadd_rn(sa, wt);
+        }
+    }
+    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb);
+    sd = wave_sum(sd); sa = wave_sum(sa);
+    if (lane == 0) {
+        const float q = __fdiv_rn(sd, sa);
+        const float m = (q != q) ? q : fmaxf(1e-10f, q);   // torch.max propagates NaN
+        const float dsp = __fdiv_rn(1.0f, m);
+        if (o.rgb) { o.rgb[ray * 3 + 0] = sr; o.rgb[ray * 3 + 1] = sg; o.rgb[ray * 3 + 2] = sb; }
+        if (o.acc) o.acc[ray] = sa;
+        if (o.disp) o.disp[ray] = dsp;
+        if (o.pixels) {
+            // clip rgb to [0,1] AFTER compositing (torch.clip passes NaN through), disparity un-clipped
+            auto clip01 = [](float v) { return (v != v) ? v : fminf(fmaxf(v, 0.f), 1.f); };
+            const f32x4 px = {clip01(sr), clip01(sg), clip01(sb), dsp};
+            *reinterpret_cast<f32x4*>(o.pixels + ray * 4) = px;
+        }
+    }
+}
+
+}  // namespace nerf_composite

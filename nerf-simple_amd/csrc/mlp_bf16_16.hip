@@ -11,10 +11,15 @@
 //     barrier per chunk; one weight fragment read from LDS (16 rows x 32 k, 1 KiB) feeds two
 //     MFMAs (the two column blocks);
 //   * the sigma head rides as row 256 of the layers_2 product, the rgb head is one 16-row tile;
-//   * a workgroup = 8 waves = a 256-point tile, persistent over tiles.
+//   * a workgroup = 8 waves = a 256-point tile, persistent over tiles;
+//   * COMP (the render path): compositing (utils/rendering.py:47-85) runs in the same launch.  A
+//     workgroup owns a contiguous range of RAYS; each tile drops its 256 x (rgb, sigma, t) into an
+//     LDS ring of 1024 samples, and whenever 8 rays are complete (or the ring is full) every wave
+//     composites one ray with the routine composite.hip uses (composite_device.h): bit-identical
+//     pixels, and raw[B,N,4] / ts[B,N] (20 B per sample) never go to HBM.
 // The chip is power/DVFS-limited on this kernel and holds a higher clock on the 16x16x32 shape
 // than on 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md, DVFS give-back item 7).
-#include "nerf_device.h"
+#include "composite_device.h"
 #include <utility>
 
 using namespace nerf_layout;
@@ -73,8 +78,16 @@ constexpr int LDS_W0 = 10 * 1024;
 constexpr int LDS_POSD = LDS_W0 + 2 * LDS_WBUF;
 constexpr int LDS_POSX = LDS_POSD + WAVES * NCB * 1024;
 constexpr int LDS_TOTAL = LDS_POSX + WAVES * NCB * 2048;
+// COMP only: the sample ring behind everything else (16 B + 4 B per sample)
+constexpr int RING_PTS = 1024;
+constexpr int LDS_RING_RAW = LDS_TOTAL;
+constexpr int LDS_RING_T = LDS_RING_RAW + RING_PTS * 16;
+constexpr int LDS_TOTAL_COMP = LDS_RING_T + RING_PTS * 4;
+constexpr int COMP_MAX_N = RING_PTS - TILE_PTS;      // an unfinished ray plus one more tile must fit
+static_assert(COMP_MAX_N == FUSED_RENDER_MAX_N, "api.hip routes by this limit");
 static_assert(B16_BIAS_FLOATS * 4 <= LDS_W0, "bias table");
-static_assert(LDS_TOTAL <= 160 * 1024 && NUM_CHUNKS % 2 == 0, "LDS budget / parity");
+static_assert(LDS_TOTAL_COMP <= 160 * 1024 && NUM_CHUNKS % 2 == 0, "LDS budget / parity");
+static_assert((RING_PTS & (RING_PTS - 1)) == 0 && RING_PTS % TILE_PTS == 0, "ring indexing");
 
 static_assert(ACT_TILE_PTS == TILE_PTS && MASK_TILE_PTS == TILE_PTS, "activation blocks and mask tiles are the kernel's tiles");
 
@@ -113,6 +126,9 @@ struct State {
                                       // fragment 0 in the tile's activation block; LOFF_INVALID past the end
     unsigned mb[NCB][2];              // ReLU mask bits being collected [column block][pair group]
     long long mask_tile;              // byte offset of this tile's dword 0 of layer 0 (nerf_layout::mask_offset_bytes), uniform
+    // fused render only (COMP)
+    long long p_end;                  // one past this workgroup's last point (uniform)
+    unsigned ring_q0;                 // ring slot of the tile's point 0 (uniform)
 };
 
 template <bool RELU>
@@ -323,7 +339,7 @@ __device__ __forceinline__ float enc_lane(TwoF q, int idx) {
 
 // SAVE (the training forward, launched in rays mode) also serves Nerf.forward(v) with gradients:
 // a.pts != NULL switches the point fetch at run time, so training needs no third instantiation.
-template <bool RAYS, bool SAVE>
+template <bool RAYS, bool SAVE, bool COMP>
 __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base, State& st) {
     const int col = c.lane & 15, g = c.lane >> 4;
     // Counter-RNG jitter: the four lane groups of a point would each evaluate the same Philox
@@ -338,7 +354,8 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
         b0 = tile_base / a.N;
         r0 = (int)(tile_base - b0 * a.N);
     }
-    const int last_local = (int)(a.P - 1 - tile_base);  // lanes past the end use the last point (results dropped)
+    const long long p_end = COMP ? st.p_end : a.P;
+    const int last_local = (int)(p_end - 1 - tile_base);  // lanes past the end use the last point (results dropped)
     if constexpr (RAYS && NCB == 2) {
         dev_rng = (a.flags & NERF_FLAG_DEVICE_RNG) && !(a.flags & NERF_FLAG_TS_GIVEN);
         if (dev_rng) {
@@ -350,9 +367,9 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         long long p = tile_base + c.wave * (16 * NCB) + cb * 16 + col;
-        const bool valid = p < a.P;
+        const bool valid = p < p_end;
         st.loff[cb] = valid ? block_lane_offset(g, c.wave * (16 * NCB) + cb * 16 + col) : LOFF_INVALID;
-        if (!valid) p = a.P - 1;
+        if (!valid) p = p_end - 1;
         PointIn pt;
         if constexpr (RAYS) {
             const float u_cb = (NCB == 2) ? __shfl(u_mine, cb * 16 + col) : 0.f;
@@ -362,7 +379,12 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
                 pt = fetch_point_pts(a, p);
             } else {
                 pt = fetch_point_rays(a, p, split_point(b0, r0, lp, a.N), u_cb, dev_rng);
-                if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
+                if constexpr (COMP) {
+                    if (valid && g == 0)
+                        lds_store<float>(((st.ring_q0 + c.wave * (16 * NCB) + cb * 16 + col) & (RING_PTS - 1)) * 4, LDS_RING_T, pt.t);
+                } else {
+                    if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
+                }
             }
         } else {
             pt = fetch_point_pts(a, p);
@@ -404,8 +426,38 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
     }
 }
 
-template <bool RAYS, bool SAVE>
+// one tile: prologue (sampling / RNG / encoding into LDS) + the 11 layers; leaves st.rgb / st.sigma
+template <bool RAYS, bool SAVE, bool COMP>
+__device__ __forceinline__ void run_tile(const Ctx& c, const MlpArgs& a, long long tile_base, State& st) {
+    stage_inputs<RAYS, SAVE, COMP>(c, a, tile_base, st);
+    run_layer<0, SAVE>(c, st, st.X, st.X);
+    run_layer<1, SAVE>(c, st, st.X, st.Y);
+    run_layer<2, SAVE>(c, st, st.Y, st.X);
+    run_layer<3, SAVE>(c, st, st.X, st.Y);
+    run_layer<4, SAVE>(c, st, st.Y, st.X);
+    run_layer<5, SAVE>(c, st, st.X, st.Y);
+    run_layer<6, SAVE>(c, st, st.Y, st.X);
+    run_layer<7, SAVE>(c, st, st.X, st.Y);
+    run_layer<8, SAVE>(c, st, st.Y, st.X);
+    run_layer<9, SAVE>(c, st, st.X, st.Y);
+    run_layer<10, SAVE>(c, st, st.Y, st.X);
+    epilogue_piece<10, 0>(0, st.pend, st.X, st);     // the rgb tile is still pending
+    for (int cb_ = 1; cb_ < NCB; ++cb_) epilogue_piece<10, 0>(4 * cb_, st.pend, st.X, st);
+}
+
+struct RingSamples {                         // a ray's samples in the workgroup's LDS ring
+    unsigned q0;                              // ring slot of its sample 0
+    __device__ __forceinline__ float t(int i) const {
+        return lds_load<float>(((q0 + (unsigned)i) & (RING_PTS - 1)) * 4, LDS_RING_T);
+    }
+    __device__ __forceinline__ f32x4 c(int i) const {
+        return lds_load<f32x4>(((q0 + (unsigned)i) & (RING_PTS - 1)) * 16, LDS_RING_RAW);
+    }
+};
+
+template <bool RAYS, bool SAVE, bool COMP>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, long long ntiles) {
+    static_assert(!COMP || (RAYS && !SAVE), "the fused render is the rays-mode inference kernel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     (void)smem;
     Ctx c;
@@ -433,38 +485,74 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
     __syncthreads();
 
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long tile_base = tile * TILE_PTS;
-        asm volatile("" : "+s"(c.wave_goff));
-        State st;
-        st.acts = reinterpret_cast<char*>(a.acts);
-        st.P = a.P;
-        st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
-        st.tile = tile;
-        stage_inputs<RAYS, SAVE>(c, a, tile_base, st);
-
-        run_layer<0, SAVE>(c, st, st.X, st.X);
-        run_layer<1, SAVE>(c, st, st.X, st.Y);
-        run_layer<2, SAVE>(c, st, st.Y, st.X);
-        run_layer<3, SAVE>(c, st, st.X, st.Y);
-        run_layer<4, SAVE>(c, st, st.Y, st.X);
-        run_layer<5, SAVE>(c, st, st.X, st.Y);
-        run_layer<6, SAVE>(c, st, st.Y, st.X);
-        run_layer<7, SAVE>(c, st, st.X, st.Y);
-        run_layer<8, SAVE>(c, st, st.Y, st.X);
-        run_layer<9, SAVE>(c, st, st.X, st.Y);
-        run_layer<10, SAVE>(c, st, st.Y, st.X);
-        epilogue_piece<10, 0>(0, st.pend, st.X, st);     // the rgb tile is still pending
-        for (int cb_ = 1; cb_ < NCB; ++cb_) epilogue_piece<10, 0>(4 * cb_, st.pend, st.X, st);
-
-        if (c.lane < 16) {
+    if constexpr (!COMP) {
+        for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const long long tile_base = tile * TILE_PTS;
+            asm volatile("" : "+s"(c.wave_goff));
+            State st;
+            st.acts = reinterpret_cast<char*>(a.acts);
+            st.P = a.P;
+            st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
+            st.tile = tile;
+            run_tile<RAYS, SAVE, false>(c, a, tile_base, st);
+            if (c.lane < 16) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) {
-                const long long p = tile_base + c.wave * (16 * NCB) + cb * 16 + c.lane;
-                if (p < a.P) {
-                    const f32x4 o = {st.rgb[cb][0], st.rgb[cb][1], st.rgb[cb][2], st.sigma[cb]};
-                    *reinterpret_cast<f32x4*>(a.raw + p * 4) = o;
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const long long p = tile_base + c.wave * (16 * NCB) + cb * 16 + c.lane;
+                    if (p < a.P) {
+                        const f32x4 o = {st.rgb[cb][0], st.rgb[cb][1], st.rgb[cb][2], st.sigma[cb]};
+                        *reinterpret_cast<f32x4*>(a.raw + p * 4) = o;
+                    }
                 }
+            }
+        }
+    } else {
+        // ---- fused render: this workgroup's contiguous range of rays, tile after tile ----------
+        const long long B = a.P / a.N;
+        const long long r_lo = (long long)blockIdx.x * B / gridDim.x, r_hi = ((long long)blockIdx.x + 1) * B / gridDim.x;
+        const long long range_base = r_lo * a.N;
+        const int n_pts = (int)((r_hi - r_lo) * a.N);                 // < 2^31: the launcher splits larger calls
+        const nerf_composite::RayOut out{a.rgb, a.disp, a.alpha, a.acc, a.w, a.pixels};
+        int next_ray = 0, n_complete = 0;                             // rays composited / completely in the ring (uniform)
+        for (int q_tile = 0; q_tile < n_pts; q_tile += TILE_PTS) {
+            const long long tile_base = range_base + q_tile;
+            asm volatile("" : "+s"(c.wave_goff));
+            State st;
+            st.acts = nullptr;
+            st.P = a.P;
+            st.mask_tile = 0;
+            st.tile = 0;
+            st.p_end = range_base + n_pts;
+            st.ring_q0 = (unsigned)q_tile & (RING_PTS - 1);
+            run_tile<true, false, true>(c, a, tile_base, st);
+            if (c.lane < 16) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    const int local = c.wave * (16 * NCB) + cb * 16 + c.lane;
+                    if (q_tile + local < n_pts) {
+                        const f32x4 o = {st.rgb[cb][0], st.rgb[cb][1], st.rgb[cb][2], st.sigma[cb]};
+                        lds_store<f32x4>(((st.ring_q0 + local) & (RING_PTS - 1)) * 16, LDS_RING_RAW, o);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                             // every wave's samples of this tile are in the ring
+            asm volatile("" ::: "memory");
+            const int done_q = q_tile + TILE_PTS < n_pts ? q_tile + TILE_PTS : n_pts;
+            while ((n_complete + 1) * a.N <= done_q) ++n_complete;
+            // composite when every wave has a ray, when the ring could not take another tile, or at the end
+            if (n_complete - next_ray >= WAVES || done_q + TILE_PTS - next_ray * a.N > RING_PTS || done_q == n_pts) {
+                for (int ray = next_ray + c.wave; ray < n_complete; ray += WAVES) {
+                    const long long gray = r_lo + ray;
+                    const float* d = a.rays + gray * 6 + 3;
+                    const float dnorm = nerf_composite::unit_dir_norm(d[0], d[1], d[2], true);
+                    const RingSamples src{(unsigned)(ray * a.N) & (RING_PTS - 1)};
+                    nerf_composite::composite_ray(src, a.N, c.lane, dnorm, gray, out);
+                }
+                next_ray = n_complete;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                         // the next tile's prologue rewrites ring slots read above
+                asm volatile("" ::: "memory");
             }
         }
     }
@@ -483,13 +571,25 @@ extern "C" int NERF_LAUNCH(const MlpArgs* args, int rays_mode, hipStream_t strea
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return (int)e;
     const long long grid = ntiles < cus ? ntiles : cus;
+    const bool comp = a.rgb || a.disp || a.acc || a.alpha || a.w || a.pixels;
+    if (comp) {
+        // fused render: rays mode, inference; a ray plus one tile must fit the LDS ring, and a
+        // workgroup's share of the points must fit an int
+        if (!rays_mode || a.acts || a.N > COMP_MAX_N || a.P / grid + a.N >= (1ll << 31)) return -2;
+        auto kern = NERF_KERNEL<true, false, true>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_TOTAL_COMP);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), LDS_TOTAL_COMP, stream, a, ntiles);
+        return (int)hipGetLastError();
+    }
 #ifdef NERF_HALF
     if (a.acts) return -2;                       // the training forward exists in bf16 only
-    auto kern = rays_mode ? NERF_KERNEL<true, false> : NERF_KERNEL<false, false>;
+    auto kern = rays_mode ? NERF_KERNEL<true, false, false> : NERF_KERNEL<false, false, false>;
 #else
     if (a.acts && !rays_mode) return -2;          // the training forward is the rays-mode instantiation (a.pts selects points)
-    auto kern = a.acts ? NERF_KERNEL<true, true>
-                       : (rays_mode ? NERF_KERNEL<true, false> : NERF_KERNEL<false, false>);
+    auto kern = a.acts ? NERF_KERNEL<true, true, false>
+                       : (rays_mode ? NERF_KERNEL<true, false, false> : NERF_KERNEL<false, false, false>);
 #endif
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);

@@ -33,6 +33,14 @@ struct MlpArgs {
     unsigned long long seed;
     int N;
     unsigned flags;
+    // fused render (sampling + MLP + compositing in one launch, mlp_bf16_16.hip COMP): per-ray outputs,
+    // any of them NULL; raw / ts_out are not written in that mode
+    float* rgb;           // [B,3]
+    float* disp;          // [B]
+    float* alpha;         // [B,N]
+    float* acc;           // [B]
+    float* w;             // [B,N]
+    float* pixels;        // [B,4] = [clip(rgb,0,1), disparity]
 };
 
 // ---- chunk barrier of the MLP kernels --------------------------------------------

@@ -27,6 +27,9 @@ namespace nerf_layout {
 
 constexpr int NUM_LAYERS = 11;
 constexpr int PARAM_COUNT = 595844;
+// largest samples-per-ray the fused render kernel composites in its LDS ring (mlp_bf16_16.hip);
+// longer rays take the two-launch path (MLP -> raw/ts in HBM -> composite.hip)
+constexpr int FUSED_RENDER_MAX_N = 768;
 
 // offsets of the 24 tensors inside the flat fp32 parameter vector
 // (PARAM_SPECS order of utils/synthetic.py == state_dict order of the reference)

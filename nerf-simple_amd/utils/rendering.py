@@ -134,7 +134,8 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
         acc = torch.empty((B,), dtype=torch.float32, device=dev)
         alpha = torch.empty((B, N), dtype=torch.float32, device=dev) if "alpha" in outputs else None
         w = torch.empty((B, N), dtype=torch.float32, device=dev) if "w" in outputs else None
-        ws = torch.empty(max(int(lib.nerf_amd_render_workspace_bytes(B, N)), 256), dtype=torch.uint8, device=dev)
+        nws = int(lib.nerf_amd_render_workspace_bytes(code, B, N))        # 0: the fused one-launch render
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws else None
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_render_forward(
                 _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)), _lib.ptr(packed), code,
@@ -299,7 +300,7 @@ def render_view(net, pose, cam_params, *, N=128, tn=2, tf=6, u=None, ray0=0, n_r
     h_pose = np.zeros((3, 4), dtype=np.float32)
     h_pose[:] = np.asarray(pose, dtype=np.float32)[:3, :4]
     pixels = torch.empty((n, 4), dtype=torch.float32, device=dev)
-    ws = torch.empty(max(int(lib.nerf_amd_render_image_workspace_bytes(n, N)), 256), dtype=torch.uint8, device=dev)
+    ws = torch.empty(max(int(lib.nerf_amd_render_image_workspace_bytes(code, n, N)), 256), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.nerf_amd_render_image_forward(
             h_pose.ctypes.data, H, W, f, int(ray0), n, _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)),

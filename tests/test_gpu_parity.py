@@ -203,6 +203,72 @@ def test_render_golden(dev, golden, synthetic, kind, precision, tol):
         assert max(errs.values()) <= tol, errs
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_fused_render_equals_two_launch_path(dev, synthetic, precision):
+    """The one-launch render (compositing out of the workgroup's LDS ring, csrc/mlp_bf16_16.hip COMP)
+    against the two-launch path (MLP -> raw / ts in HBM -> csrc/composite.hip) through the C ABI:
+    all five outputs and the clipped pixels BIT-identical, for rays that fit a tile exactly
+    (N = 32, 64, 128), straddle tiles (N = 192, 100, 65, 3), fill the ring (N = 768), with ragged
+    ray counts (workgroups get uneven ray ranges, last tiles are partial) and explicit / device jitter."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    lib = _lib.lib()
+    net = make_net(synthetic, dev, "structured", precision)
+    code = _lib.precision_code(precision)
+    packed = net.packed_weights(code)
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 20)).float()
+    allrays = camera_rays([pose], [64, 64, synthetic.focal_from_fov(64)]).float().contiguous().to(dev)
+    st = _lib.stream_ptr(dev)
+    for B, N, dev_rng in ((777, 32, False), (2048, 64, True), (1000, 128, False), (333, 192, True), (257, 100, False),
+                          (100, 65, True), (4096, 3, False), (40, 768, False), (1, 128, True), (3000, 128, True)):
+        rays = allrays[:B].contiguous()
+        assert lib.nerf_amd_render_workspace_bytes(code, B, N) == 0
+        u = None if dev_rng else torch.rand(B, N, generator=torch.Generator().manual_seed(B + N)).to(dev)
+        flags = _lib.FLAG_DEVICE_RNG if dev_rng else 0
+        tb = torch.linspace(2, 6, N + 1).to(dev)
+        raw = torch.empty(B, N, 4, device=dev)
+        ts = torch.empty(B, N, device=dev)
+        _lib.check(lib.nerf_amd_mlp_forward_rays(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tb), _lib.ptr(packed), code, flags, 9,
+                                                 500, _lib.ptr(raw), _lib.ptr(ts), B, N, st), "mlp_forward_rays")
+        two = [torch.full(s_, 7.0, device=dev) for s_ in ((B, 3), (B,), (B, N), (B,), (B, N))]
+        _lib.check(lib.nerf_amd_volume_render_rays(_lib.ptr(raw), _lib.ptr(ts), _lib.ptr(rays), *[_lib.ptr(x) for x in two],
+                                                   B, N, st), "volume_render_rays")
+        px2 = torch.empty(B, 4, device=dev)
+        _lib.check(lib.nerf_amd_volume_render_pixels(_lib.ptr(raw), _lib.ptr(ts), _lib.ptr(rays), _lib.ptr(px2), B, N, st),
+                   "volume_render_pixels")
+        one = [torch.full(s_, -7.0, device=dev) for s_ in ((B, 3), (B,), (B, N), (B,), (B, N))]
+        _lib.check(lib.nerf_amd_render_forward(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tb), _lib.ptr(packed), code, flags, 9, 500,
+                                               *[_lib.ptr(x) for x in one], None, B, N, st), "render_forward")
+        px1 = torch.full((B + 8, 4), -7.0, device=dev)          # 8 sentinel rows behind the output
+        _lib.check(lib.nerf_amd_render_pixels_forward(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tb), _lib.ptr(packed), code, flags,
+                                                      9, 500, _lib.ptr(px1), None, B, N, st), "render_pixels_forward")
+        # alpha / w skipped: the other outputs do not change
+        slim = [torch.full(s_, -7.0, device=dev) for s_ in ((B, 3), (B,), (B,))]
+        _lib.check(lib.nerf_amd_render_forward(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tb), _lib.ptr(packed), code, flags, 9, 500,
+                                               _lib.ptr(slim[0]), _lib.ptr(slim[1]), None, _lib.ptr(slim[2]), None, None, B, N, st),
+                   "render_forward")
+        torch.cuda.synchronize()
+        for n, a, b in zip(NAMES, one, two):
+            assert torch.equal(a, b), (B, N, n, float((a - b).abs().max()))
+        assert torch.equal(px1[:B], px2) and bool((px1[B:] == -7.0).all()), (B, N)
+        assert torch.equal(slim[0], two[0]) and torch.equal(slim[1], two[1]) and torch.equal(slim[2], two[3])
+    # a ray longer than the ring takes the two-launch path inside the same entry point (workspace needed)
+    B, N = 5, 800
+    rays = allrays[:B].contiguous()
+    u = torch.rand(B, N, generator=torch.Generator().manual_seed(1)).to(dev)
+    tb = torch.linspace(2, 6, N + 1).to(dev)
+    nws = int(lib.nerf_amd_render_workspace_bytes(code, B, N))
+    assert nws >= B * N * 20
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+    out = [torch.empty(s_, device=dev) for s_ in ((B, 3), (B,), (B, N), (B,), (B, N))]
+    assert lib.nerf_amd_render_forward(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tb), _lib.ptr(packed), code, 0, 0, 0,
+                                       *[_lib.ptr(x) for x in out], None, B, N, st) == -1          # no workspace: EINVAL
+    _lib.check(lib.nerf_amd_render_forward(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tb), _lib.ptr(packed), code, 0, 0, 0,
+                                           *[_lib.ptr(x) for x in out], _lib.ptr(ws), B, N, st), "render_forward")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[0]).all() and torch.allclose(out[4].sum(1), out[3], rtol=1e-5, atol=1e-6)
+
+
 def test_render_rng_consumption(dev, golden, synthetic):
     """Default mode draws ONE torch.rand(B,N) from the CPU generator per call,
     like the reference (utils/rendering.py:28): seeding reproduces the golden."""

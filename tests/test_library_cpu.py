@@ -38,13 +38,17 @@ def test_header_symbols_exported(lib):
 
 
 def test_introspection(lib):
-    assert lib.nerf_amd_abi_version() == 1
+    assert lib.nerf_amd_abi_version() == 2
     assert lib.nerf_amd_param_count() == 595844
     assert lib.nerf_amd_packed_bytes(1) == lib.nerf_amd_packed_bytes(2) == 1172 * 1024 + 2464 * 4
     assert lib.nerf_amd_packed_bytes(0) == 2360 * 1024 + 154 * 16 * 4
     assert lib.nerf_amd_packed_bytes(7) < 0
-    assert lib.nerf_amd_render_workspace_bytes(16000, 128) >= 16000 * 128 * 20
-    assert lib.nerf_amd_render_workspace_bytes(-1, 128) < 0
+    assert lib.nerf_amd_render_workspace_bytes(0, 16000, 128) >= 16000 * 128 * 20       # fp32: raw + ts
+    assert lib.nerf_amd_render_workspace_bytes(1, 16000, 128) == 0                      # 16-bit: one fused launch
+    assert lib.nerf_amd_render_workspace_bytes(2, 16000, 768) == 0
+    assert lib.nerf_amd_render_workspace_bytes(1, 100, 769) >= 100 * 769 * 20           # ray longer than the LDS ring
+    assert lib.nerf_amd_render_workspace_bytes(1, -1, 128) < 0
+    assert lib.nerf_amd_render_image_workspace_bytes(1, 1000, 128) == 24064             # the ray table only
 
 
 def test_layout_selfcheck(lib):
@@ -134,7 +138,7 @@ def test_abi_argument_errors(lib):
     assert lib.nerf_amd_volume_render_backward(one, one, one, 3, one, null, null, null, null, one, 4, 1024, null) == EUNSUP
     assert lib.nerf_amd_render_forward(one, null, one, one, 1, 0, 0, 0, one, one, null, one, null, one, 4, 8, null) == EINVAL  # no jitter
     assert lib.nerf_amd_render_forward(one, one, null, one, 1, 0, 0, 0, one, one, null, one, null, one, 4, 8, null) == EINVAL  # no tbins
-    assert lib.nerf_amd_render_forward(one, one, one, one, 1, 0, 0, 0, one, one, null, one, null, null, 4, 8, null) == EINVAL  # no workspace
+    assert lib.nerf_amd_render_forward(one, one, one, one, 0, 0, 0, 0, one, one, null, one, null, null, 4, 8, null) == EINVAL  # no workspace on the two-launch (fp32) path
     assert lib.nerf_amd_sample_pdf(one, one, one, 0, 0, 0, one, 4, 2, 8, null) == EUNSUP      # Nc < 3
     assert lib.nerf_amd_sample_pdf(one, one, one, 0, 0, 0, one, 4, 300, 8, null) == EUNSUP    # Nc > 256
     assert lib.nerf_amd_generate_rays(one, 10, 10, ctypes.c_float(5.0), 90, 20, one, null) == EINVAL   # past the image
@@ -182,7 +186,7 @@ def test_counted_vmcnt_waits():
         import check_vmcnt
     finally:
         sys.path.pop(0)
-    for src, kernels, waits in (("mlp_bf16_16.hip", 3, 41), ("mlp_bwd_16.hip", 1, 39)):
+    for src, kernels, waits in (("mlp_bf16_16.hip", 4, 41), ("mlp_bwd_16.hip", 1, 39)):
         asm = check_vmcnt.assemble(os.path.join(root, "nerf-simple_amd", "csrc", src))
         res = {k: check_vmcnt.check_kernel(v) for k, v in check_vmcnt.kernels_of(asm).items()}
         assert len(res) == kernels, (src, list(res))

@@ -59,7 +59,7 @@ class Variant:
         h.nerf_amd_mlp_forward_rays.argtypes = [vp, vp, vp, vp, i32, u32, u64, i64, vp, vp, i64, i32, vp]
         if self.fused:
             h.nerf_amd_render_pixels_forward.restype = i32
-            h.nerf_amd_render_pixels_forward.argtypes = [vp, vp, vp, vp, i32, u32, u64, i64, vp, i64, i32, vp]
+            h.nerf_amd_render_pixels_forward.argtypes = [vp, vp, vp, vp, i32, u32, u64, i64, vp, vp, i64, i32, vp]
         self.h = h
         self.packed = torch.empty(h.nerf_amd_packed_bytes(self.precision), dtype=torch.uint8, device=dev)
         _lib.check(h.nerf_amd_pack_weights(_lib.ptr(flat), _lib.ptr(self.packed), self.precision,
@@ -70,7 +70,7 @@ class Variant:
         if self.fused:
             _lib.check(self.h.nerf_amd_render_pixels_forward(
                 _lib.ptr(rays), None, _lib.ptr(tb), _lib.ptr(self.packed), self.precision, 2, 1234, 0,
-                _lib.ptr(pixels), B, N, _lib.stream_ptr(dev)), "render_pixels")
+                _lib.ptr(pixels), None, B, N, _lib.stream_ptr(dev)), "render_pixels")
         else:
             _lib.check(self.h.nerf_amd_mlp_forward_rays(
                 _lib.ptr(rays), None, _lib.ptr(tb), _lib.ptr(self.packed), self.precision, 2, 1234, 0,
