@@ -184,6 +184,22 @@ int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u,
                         uint32_t flags, uint64_t seed, int64_t ray_id0,
                         float* ts_out, int64_t B, int Nc, int Nf, void* stream);
 
+/* BASELINE config 4 as ONE call for pixels [ray0, ray0+n_rays) of an HxW view: device ray generation ->
+ * coarse render (Nc stratified samples, network `packed_c`; only its positions and weights are kept)
+ * -> nerf_amd_sample_pdf -> fine render of `packed_f` on the Nc+Nf merged positions ->
+ * pixels[n_rays,4] = [clip(rgb,0,1), disparity].  Four launches, no host sync, nothing per-sample but
+ * ts / w of the coarse pass and ts of the fine pass touches HBM.  u_c[n,Nc] / u_f[n,Nf] explicit
+ * uniforms, or NERF_AMD_DEVICE_RNG (both keyed by the global pixel id: sharding-invariant).
+ * 16-bit precisions, Nc+Nf <= 512; otherwise NERF_AMD_EUNSUP (compose the three stages instead).
+ * Parity unpinned like nerf_amd_sample_pdf (the reference has no hierarchical sampling). */
+int64_t nerf_amd_render_hierarchical_workspace_bytes(int64_t n_rays, int Nc, int Nf);
+int nerf_amd_render_hierarchical_forward(const float* h_pose, int H, int W, float f,
+                                         int64_t ray0, int64_t n_rays,
+                                         const float* u_c, const float* u_f, const float* tbins_c,
+                                         const void* packed_c, const void* packed_f, int precision,
+                                         uint32_t flags, uint64_t seed,
+                                         float* pixels, void* workspace, int Nc, int Nf, void* stream);
+
 /* Training-side front end: sampling + point assembly + encoding in one launch
  * (utils/rendering.py:24-40 + utils/xyz.py:16-36): rays[B,6] (+ u / ts / device
  * RNG as in nerf_amd_render_forward) -> posx[B*N,63], posd[B*N,27], ts[B,N]

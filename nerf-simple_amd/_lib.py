@@ -56,6 +56,9 @@ _SIGNATURES = {
     "nerf_amd_render_image_forward": (_i32, [_vp, _i32, _i32, ctypes.c_float, _i64, _i64, _vp, _vp, _vp, _i32,
                                              _u32, _u64, _vp, _vp, _i32, _vp]),
     "nerf_amd_sample_pdf": (_i32, [_vp, _vp, _vp, _u32, _u64, _i64, _vp, _i64, _i32, _i32, _vp]),
+    "nerf_amd_render_hierarchical_workspace_bytes": (_i64, [_i64, _i32, _i32]),
+    "nerf_amd_render_hierarchical_forward": (_i32, [_vp, _i32, _i32, ctypes.c_float, _i64, _i64, _vp, _vp, _vp, _vp, _vp,
+                                                    _i32, _u32, _u64, _vp, _vp, _i32, _i32, _vp]),
     "nerf_amd_train_activation_bytes": (_i64, [_i64]),
     "nerf_amd_mlp_forward_train": (_i32, [_vp, _vp, _vp, _vp, _u32, _u64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_mlp_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),

@@ -328,6 +328,46 @@ int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u, uint32_
                                       (flags & NERF_AMD_DEVICE_RNG) ? 1 : 0, S(stream));
 }
 
+int64_t nerf_amd_render_hierarchical_workspace_bytes(int64_t n_rays, int Nc, int Nf) {
+    if (n_rays < 0 || Nc <= 0 || Nf < 0) return NERF_AMD_EINVAL;
+    // rays[n,6] + ts_c[n,Nc] + w_c[n,Nc] + ts_f[n,Nc+Nf]
+    return align_up(n_rays * 24, 256) + 2 * align_up(n_rays * Nc * 4, 256) + align_up(n_rays * (int64_t)(Nc + Nf) * 4, 256);
+}
+
+int nerf_amd_render_hierarchical_forward(const float* h_pose, int H, int W, float f, int64_t ray0, int64_t n_rays,
+                                         const float* u_c, const float* u_f, const float* tbins_c,
+                                         const void* packed_c, const void* packed_f, int precision, uint32_t flags,
+                                         uint64_t seed, float* pixels, void* workspace, int Nc, int Nf, void* stream) {
+    if (n_rays < 0 || Nc <= 0 || Nf < 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
+    if (n_rays == 0) return 0;
+    if (Nc < 3 || Nc > 256 || Nc + Nf > 512 || !fused_render(precision, Nc + Nf)) return NERF_AMD_EUNSUP;
+    if (!workspace || !pixels || !packed_c || !packed_f || !tbins_c) return NERF_AMD_EINVAL;
+    if (flags & NERF_AMD_TS_GIVEN) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_DEVICE_RNG) && (!u_c || (!u_f && Nf > 0))) return NERF_AMD_EINVAL;
+    char* ws = reinterpret_cast<char*>(workspace);
+    float* rays = reinterpret_cast<float*>(ws);
+    ws += align_up(n_rays * 24, 256);
+    float* ts_c = reinterpret_cast<float*>(ws);
+    ws += align_up(n_rays * Nc * 4, 256);
+    float* w_c = reinterpret_cast<float*>(ws);
+    ws += align_up(n_rays * Nc * 4, 256);
+    float* ts_f = reinterpret_cast<float*>(ws);
+    int rc = nerf_amd_generate_rays(h_pose, H, W, f, ray0, n_rays, rays, stream);
+    if (rc) return rc;
+    // coarse pass: one fused launch that leaves only what the sampler needs (positions and weights)
+    MlpArgs a{};
+    a.rays = rays; a.u = u_c; a.tbins = tbins_c; a.packed = packed_c; a.ts_out = ts_c; a.w = w_c;
+    a.P = n_rays * (int64_t)Nc; a.N = Nc; a.flags = flags; a.seed = seed; a.ray_id0 = ray0;
+    rc = launch_mlp(a, 1, precision, S(stream));
+    if (rc) return rc;
+    rc = nerf_amd_launch_sample_pdf(ts_c, w_c, u_f, ts_f, n_rays, Nc, Nf, seed, ray0,
+                                    (flags & NERF_AMD_DEVICE_RNG) ? 1 : 0, S(stream));
+    if (rc) return rc;
+    // fine pass on the merged, sorted positions -> clipped pixels
+    return nerf_amd_render_pixels_forward(rays, ts_f, nullptr, packed_f, precision, NERF_AMD_TS_GIVEN, seed, ray0, pixels,
+                                          nullptr, n_rays, Nc + Nf, stream);
+}
+
 int64_t nerf_amd_train_activation_bytes(int64_t P) {
     return P < 0 ? (int64_t)NERF_AMD_EINVAL : (int64_t)acts_total_bytes(P);
 }

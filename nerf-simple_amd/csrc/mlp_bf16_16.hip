@@ -382,9 +382,8 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
                 if constexpr (COMP) {
                     if (valid && g == 0)
                         lds_store<float>(((st.ring_q0 + c.wave * (16 * NCB) + cb * 16 + col) & (RING_PTS - 1)) * 4, LDS_RING_T, pt.t);
-                } else {
-                    if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
                 }
+                if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
             }
         } else {
             pt = fetch_point_pts(a, p);

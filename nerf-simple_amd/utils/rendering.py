@@ -356,28 +356,87 @@ def render_hierarchical(rays, net_coarse, net_fine, Nc=64, Nf=128, tn=2, tf=6, *
     stratified samples, sample_pdf on its weights, and a second render_nerf pass
     of ``net_fine`` on the merged Nc+Nf positions (explicit ts).  Each pass is the
     pinned render_nerf; only the sampler in between is unpinned.
-    Returns (fine 5-tuple, coarse 5-tuple, ts_fine)."""
+    Returns (fine 5-tuple, coarse 5-tuple, ts_fine).  Every arithmetic step runs in the library
+    (sample positions come out of the kernel); see render_hierarchical_view for the one-call form."""
     _lib.require_cuda_f32(rays, "rays")
     dev, B = rays.device, rays.size(0)
+    rays = rays.detach().contiguous()
+    code = _lib.precision_code(net_coarse.precision if precision is None else precision)
+    packed = net_coarse.packed_weights(code)
+    flags, jit = _lib.FLAG_DEVICE_RNG, None
     if u_c is None and not device_rng:
         u_c, pending_rng = reference_rand(B, Nc, dev)
         pending_rng.finish()
     if u_c is not None:
-        tb = _tbins(tn, tf, Nc, dev)
-        ts_c = (tb[1] - tb[0]) * u_c + tb[:-1]
-        coarse = render_nerf(rays, net_coarse, Nc, tn, tf, ts=ts_c, precision=precision)
-    else:
-        # device RNG: recover the positions the kernel drew through the stage-1 entry point
-        code = _lib.precision_code(net_coarse.precision if precision is None else precision)
-        raw = torch.empty((B, Nc, 4), dtype=torch.float32, device=dev)
-        ts_c = torch.empty((B, Nc), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
-            _lib.check(_lib.lib().nerf_amd_mlp_forward_rays(
-                _lib.ptr(rays.contiguous()), None, _lib.ptr(_tbins(tn, tf, Nc, dev)),
-                _lib.ptr(net_coarse.packed_weights(code)), code, _lib.FLAG_DEVICE_RNG, int(seed), int(ray_id0),
-                _lib.ptr(raw), _lib.ptr(ts_c), B, Nc, _lib.stream_ptr(dev)), "nerf_amd_mlp_forward_rays")
-        dn = rays[:, 3:] / torch.norm(rays[:, 3:], dim=1, keepdim=True)
-        coarse = volume_render(raw, ts_c, dn.contiguous())
+        flags, jit = 0, _lib.require_cuda_f32(u_c, "u_c").contiguous()
+    # the coarse pass through the stage-1 entry point: the sampler needs the positions the kernel drew
+    lib = _lib.lib()
+    raw = torch.empty((B, Nc, 4), dtype=torch.float32, device=dev)
+    ts_c = torch.empty((B, Nc), dtype=torch.float32, device=dev)
+    outs = [torch.empty(s_, dtype=torch.float32, device=dev) for s_ in ((B, 3), (B,), (B, Nc), (B,), (B, Nc))]
+    with torch.cuda.device(dev):
+        st = _lib.stream_ptr(dev)
+        _lib.check(lib.nerf_amd_mlp_forward_rays(
+            _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, Nc, dev)), _lib.ptr(packed), code, flags, int(seed),
+            int(ray_id0), _lib.ptr(raw), _lib.ptr(ts_c), B, Nc, st), "nerf_amd_mlp_forward_rays")
+        _lib.check(lib.nerf_amd_volume_render_rays(_lib.ptr(raw), _lib.ptr(ts_c), _lib.ptr(rays),
+                                                   *[_lib.ptr(x) for x in outs], B, Nc, st), "nerf_amd_volume_render_rays")
+    coarse = tuple(outs)
     ts_f = sample_pdf(ts_c, coarse[4], Nf, u=u_f, device_rng=device_rng, seed=seed, ray_id0=ray_id0)
     fine = render_nerf(rays, net_fine, Nc + Nf, tn, tf, ts=ts_f, precision=precision)
     return fine, coarse, ts_f
+
+
+def render_hierarchical_view(net_coarse, net_fine, pose, cam_params, Nc=64, Nf=128, *, tn=2, tf=6, u_c=None, u_f=None,
+                             ray0=0, n_rays=None, precision=None, device_rng=False, seed=0):
+    """BASELINE config 4 for one view (or its pixel range [ray0, ray0+n_rays)) in ONE library call:
+    device ray generation -> coarse pass (Nc stratified samples) -> sample_pdf -> fine pass on the
+    Nc+Nf merged positions -> clip(rgb,0,1)  (nerf_amd_render_hierarchical_forward: four launches,
+    no torch arithmetic on the path).  Returns pixels [n,4] = [r,g,b,disparity] on the GPU.
+    u_c [n,Nc] / u_f [n,Nf]: explicit uniforms for these pixels; default: the reference-style CPU
+    draws torch.rand(n,Nc) then torch.rand(n,Nf); device_rng=True: counter RNG keyed by global pixel id.
+    16-bit precisions only (the fused render kernels); parity unpinned (no reference counterpart)."""
+    import numpy as np
+    dev = next(net_coarse.parameters()).device
+    H, W, f = int(cam_params[0]), int(cam_params[1]), float(cam_params[2])
+    n = H * W - ray0 if n_rays is None else int(n_rays)
+    code = _lib.precision_code(net_coarse.precision if precision is None else precision)
+    pc, pf = net_coarse.packed_weights(code), net_fine.packed_weights(code)
+    flags = 0
+    if device_rng:
+        flags, u_c, u_f = _lib.FLAG_DEVICE_RNG, None, None
+    else:
+        if u_c is None:
+            u_c, pend = reference_rand(n, Nc, dev)
+            pend.finish()
+        if u_f is None:
+            u_f, pend = reference_rand(n, Nf, dev)
+            pend.finish()
+        u_c = _lib.require_cuda_f32(u_c, "u_c").contiguous()
+        u_f = _lib.require_cuda_f32(u_f, "u_f").contiguous()
+    lib = _lib.lib()
+    h_pose = np.zeros((3, 4), dtype=np.float32)
+    h_pose[:] = np.asarray(pose, dtype=np.float32)[:3, :4]
+    pixels = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    ws = torch.empty(max(int(lib.nerf_amd_render_hierarchical_workspace_bytes(n, Nc, Nf)), 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nerf_amd_render_hierarchical_forward(
+            h_pose.ctypes.data, H, W, f, int(ray0), n, _lib.ptr(u_c), _lib.ptr(u_f), _lib.ptr(_tbins(tn, tf, Nc, dev)),
+            _lib.ptr(pc), _lib.ptr(pf), code, flags, int(seed), _lib.ptr(pixels), _lib.ptr(ws), int(Nc), int(Nf),
+            _lib.stream_ptr(dev)), "nerf_amd_render_hierarchical_forward")
+    return pixels
+
+
+def render_hierarchical_sharded(net_coarse, net_fine, pose, cam_params, Nc=64, Nf=128, *, group=None, **kw):
+    """Multi-GPU config 4: rank r renders its contiguous pixel range coarse+fine in one library call and
+    ONE all-gather assembles pixels [H*W,4] on every rank.  Jitter is keyed by global pixel id
+    (device RNG) or sliced from the caller's u_c / u_f, so the image does not depend on the world size."""
+    from .. import parallel
+    rank, world = parallel.world_info(group)
+    n = int(cam_params[0]) * int(cam_params[1])
+    lo, hi = parallel.shard_range(n, rank, world)
+    u_c, u_f = kw.pop("u_c", None), kw.pop("u_f", None)
+    shard = render_hierarchical_view(net_coarse, net_fine, pose, cam_params, Nc, Nf, ray0=lo, n_rays=hi - lo,
+                                     u_c=None if u_c is None else u_c[lo:hi], u_f=None if u_f is None else u_f[lo:hi],
+                                     **kw)
+    return parallel.gather_pixels(shard, n, group)

@@ -1,0 +1,64 @@
+"""Worker of tests/test_gpu_multirank.py: one rank of a 2-rank job on ONE GPU (gloo rendezvous, both
+ranks on cuda:0), running the HIP path under a process group.  Results go to the directory in argv[1]."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_dir = sys.argv[1]
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo")
+    from nerf_simple_amd import _lib, parallel
+    from nerf_simple_amd.optim import FusedAdam
+    from nerf_simple_amd.training import GraphedTrainStep
+    from nerf_simple_amd.utils import synthetic
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import render_view_sharded, render_hierarchical_sharded
+    from nerf_simple_amd.utils.xyz import spherical_to_pose
+    _lib.lib()
+    res = {}
+    pose = spherical_to_pose(4, -30, 35)
+    cam = [40, 36, synthetic.focal_from_fov(40)]               # 1440 pixels: 720 per rank
+    net = Nerf(precision="fp16").to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "structured"))
+    fine = Nerf(precision="fp16").to(dev)
+    fine.load_state_dict(synthetic.synthetic_state_dict(7, "structured"))
+    with torch.no_grad():
+        res["view"] = render_view_sharded(net, pose, cam, N=64, device_rng=True, seed=11).cpu().numpy()
+        u = torch.rand(cam[0] * cam[1], 48, generator=torch.Generator().manual_seed(3)).to(dev)
+        res["view_u"] = render_view_sharded(net, pose, cam, N=48, u=u).cpu().numpy()
+        res["hier"] = render_hierarchical_sharded(net, fine, pose, cam, 64, 128, device_rng=True, seed=5).cpu().numpy()
+    # data-parallel training step: each rank holds half of golden G6's rays
+    g = np.load(os.path.join(ROOT, "tests", "golden", "train.npz"))
+    rays, gt, uu, N = (torch.from_numpy(np.ascontiguousarray(g[k])) for k in ("rays", "gt", "u")) + (int(g["N"]),)
+    half = rays.shape[0] // world
+    sl = slice(rank * half, (rank + 1) * half)
+    tnet = Nerf(precision="bf16").to(dev)
+    tnet.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+    parallel.broadcast_parameters(tnet)
+    opt = FusedAdam(tnet, lr=5e-4)
+    stepper = GraphedTrainStep(tnet, opt, half, N, group=dist.group.WORLD)
+    loss = stepper.step(rays[sl].to(dev), gt[sl].to(dev), u=uu[sl].to(dev))
+    torch.cuda.synchronize()
+    res["grads"] = stepper.grads.cpu().numpy()
+    res["loss"] = np.array([float(loss)])
+    res["params"] = opt.flat.cpu().numpy()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "rank0.npz"), **res)
+    else:
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=res["loss"], params=res["params"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,111 @@
+"""The HIP path under a process group on the GPU box: two ranks share the one test GPU (gloo
+rendezvous on 127.0.0.1), so the sharded render drivers and the data-parallel training step run
+exactly as they do with one GPU per rank, minus RCCL (BASELINE configs 4 and 5)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture(scope="module")
+def two_rank_results(tmp_path_factory):
+    assert torch.cuda.is_available()
+    out = tmp_path_factory.mktemp("two_rank")
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_two_rank_worker.py"), str(out)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode(errors="replace") for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    return np.load(out / "rank0.npz"), np.load(out / "rank1.npz")
+
+
+def _nets(dev, synthetic):
+    from nerf_simple_amd.utils.nets import Nerf
+    net = Nerf(precision="fp16").to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "structured"))
+    fine = Nerf(precision="fp16").to(dev)
+    fine.load_state_dict(synthetic.synthetic_state_dict(7, "structured"))
+    return net, fine
+
+
+def test_sharded_renders_equal_unsharded(two_rank_results, synthetic):
+    """render_view_sharded / render_hierarchical_sharded on 2 ranks == the same view rendered by one
+    process, bit for bit (jitter keyed by global pixel id or sliced from the caller's table)."""
+    from nerf_simple_amd.utils.rendering import render_view, render_hierarchical_view
+    from nerf_simple_amd.utils.xyz import spherical_to_pose
+    r0, _ = two_rank_results
+    dev = torch.device("cuda:0")
+    net, fine = _nets(dev, synthetic)
+    pose = spherical_to_pose(4, -30, 35)
+    cam = [40, 36, synthetic.focal_from_fov(40)]
+    with torch.no_grad():
+        one = render_view(net, pose, cam, N=64, device_rng=True, seed=11).cpu().numpy()
+        u = torch.rand(cam[0] * cam[1], 48, generator=torch.Generator().manual_seed(3)).to(dev)
+        one_u = render_view(net, pose, cam, N=48, u=u).cpu().numpy()
+        hier = render_hierarchical_view(net, fine, pose, cam, 64, 128, device_rng=True, seed=5).cpu().numpy()
+    assert r0["view"].shape == (1440, 4) and np.array_equal(r0["view"], one)
+    assert np.array_equal(r0["view_u"], one_u)
+    assert np.array_equal(r0["hier"], hier)
+    assert np.isfinite(hier).all() and hier[:, :3].min() >= 0 and hier[:, :3].max() <= 1
+
+
+def test_data_parallel_step_equals_global_batch(two_rank_results, golden, synthetic):
+    """GraphedTrainStep(group=...) on 2 ranks x 32 rays: the all-reduced gradient equals the gradient of
+    the 64-ray global batch computed by one process (equal shards, per-rank MSE mean; train.py:52-54),
+    both ranks end with identical parameters, and the mean of the rank losses is the global loss."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.training import train_step
+    r0, r1 = two_rank_results
+    dev = torch.device("cuda:0")
+    g = golden("train.npz")
+    rays, gt, u, N = (torch.from_numpy(np.ascontiguousarray(g[k])).to(dev) for k in ("rays", "gt", "u")) + (int(g["N"]),)
+    net = Nerf(precision="bf16").to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    loss = float(train_step(net, opt, rays, gt, N, u=u))
+    want = torch.cat([p.grad.reshape(-1) for p in net.parameters()]).cpu().numpy()
+    got = r0["grads"]
+    # the same kernels on the same points; only the float-atomic summation order and the split of the
+    # mean over two ranks differ
+    assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), np.abs(got - want).max() / np.abs(want).max()
+    assert abs(0.5 * (float(r0["loss"][0]) + float(r1["loss"][0])) - loss) <= 1e-5 * loss
+    assert np.array_equal(r0["params"], r1["params"])
+
+
+@pytest.mark.parametrize("mode", ["render", "train"])
+def test_bench_self_launch_two_ranks(mode):
+    """`python bench.py --gpus 2` starts its own rank processes (no torch.distributed.run needed) and
+    rank 0 prints the one JSON line; rehearsed here with both ranks on the one GPU over gloo."""
+    env = dict(os.environ, NERF_BENCH_BACKEND="gloo", NERF_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--mode", mode], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks"]["world_size"] == 2 and res["ranks"]["rank_sum_check"] is True
+    assert res["value"] > 0 and res["steps"] == 2
+    assert res["scaling"] == ("strong" if mode == "render" else "weak")
