@@ -39,7 +39,8 @@ def main():
         res["hier"] = render_hierarchical_sharded(net, fine, pose, cam, 64, 128, device_rng=True, seed=5).cpu().numpy()
     # data-parallel training step: each rank holds half of golden G6's rays
     g = np.load(os.path.join(ROOT, "tests", "golden", "train.npz"))
-    rays, gt, uu, N = (torch.from_numpy(np.ascontiguousarray(g[k])) for k in ("rays", "gt", "u")) + (int(g["N"]),)
+    rays, gt, uu = (torch.from_numpy(np.ascontiguousarray(g[k])) for k in ("rays", "gt", "u"))
+    N = int(g["N"])
     half = rays.shape[0] // world
     sl = slice(rank * half, (rank + 1) * half)
     tnet = Nerf(precision="bf16").to(dev)

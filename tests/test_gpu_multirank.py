@@ -79,7 +79,8 @@ def test_data_parallel_step_equals_global_batch(two_rank_results, golden, synthe
     r0, r1 = two_rank_results
     dev = torch.device("cuda:0")
     g = golden("train.npz")
-    rays, gt, u, N = (torch.from_numpy(np.ascontiguousarray(g[k])).to(dev) for k in ("rays", "gt", "u")) + (int(g["N"]),)
+    rays, gt, u = (torch.from_numpy(np.ascontiguousarray(g[k])).to(dev) for k in ("rays", "gt", "u"))
+    N = int(g["N"])
     net = Nerf(precision="bf16").to(dev)
     net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
     opt = torch.optim.SGD(net.parameters(), lr=0.0)

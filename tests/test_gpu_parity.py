@@ -2,17 +2,17 @@
 mirror) against the golden vectors captured from the reference and against
 the CPU oracle on seeded inputs.
 
-Tolerances (stated once, used below):
+Tolerances (stated once, used below; errors are max-abs / max(1, max|ref|)):
   ENC_ATOL   encoder vs torch-CPU: ocml sinf/cosf on the exactly scaled
              argument, ~1-2 ulp of a value in [-1,1].
-  F32_*      exact-f32 MFMA path vs CPU fp32: same arithmetic, different
-             summation order (k-permuted fma chain vs MKL sgemm blocking) through
-             12 layers; observed ~1e-6 relative, bound 1e-4 of the output scale.
-  BF16_*     bf16 operands (8-bit mantissa) with fp32 accumulation: ~3e-3
-             relative per layer, bound 4e-2 of the output scale; the image-level
-             criterion is PSNR (test_image_psnr).
-  FP16_TOL   fp16 operands (11-bit mantissa): 8x tighter than bf16; observed ~2e-3
-             on the structured weights.
+  TOL[(precision, weight set)]  the MLP and the whole render against the goldens, at <= 3x the
+             error observed on MI355X:
+               fp32  exact-f32 MFMA: same arithmetic, different summation order (k-permuted fma
+                     chain vs MKL sgemm blocking) through 12 layers: 1.5e-7 / 3.6e-5 observed
+               fp16  11-bit mantissa operands, fp32 accumulate: 6e-5 / 2.4e-3 observed
+               bf16  8-bit mantissa operands: 7e-4 / 1.6e-2 observed
+             ("default" = nn.Linear-scale weights, "structured" = He-scale hidden weights with x8
+             head gains); the image-level criterion is PSNR (test_image_psnr).
   CMP_RTOL   compositor alone: identical formulas, scan order differs from
              torch.cumprod's sequential order by a few ulp.
 """
@@ -23,9 +23,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ENC_ATOL = 5e-7
-F32_TOL = 1e-4
-BF16_TOL = 4e-2
-FP16_TOL = 5e-3           # 11-bit mantissa: 8x below bf16
+TOL = {("fp32", "default"): 5e-7, ("fp32", "structured"): 1e-4,
+       ("fp16", "default"): 2e-4, ("fp16", "structured"): 7e-3,
+       ("bf16", "default"): 2e-3, ("bf16", "structured"): 4.5e-2}
+F32_TOL = TOL[("fp32", "structured")]
 CMP_RTOL = 2e-5
 CMP_ATOL = 1e-6
 NAMES = ("rgb", "disp", "alpha", "acc", "w")
@@ -90,8 +91,9 @@ def test_encode_empty_and_other_levels(dev, oracle):
 
 # ---------------------------------------------------------------- the MLP
 @pytest.mark.parametrize("kind", ["default", "structured"])
-@pytest.mark.parametrize("precision,tol", [("fp32", F32_TOL), ("bf16", BF16_TOL), ("fp16", FP16_TOL)])
-def test_mlp_golden(dev, golden, synthetic, kind, precision, tol):
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+def test_mlp_golden(dev, golden, synthetic, kind, precision):
+    tol = TOL[(precision, kind)]
     g = golden(f"mlp_{kind}.npz")
     net = make_net(synthetic, dev, kind, precision)
     with torch.no_grad():
@@ -105,20 +107,58 @@ def test_mlp_golden(dev, golden, synthetic, kind, precision, tol):
 
 @pytest.mark.parametrize("P", [1, 31, 257, 1000])
 def test_mlp_ragged_sizes(dev, oracle, synthetic, P):
-    """Tiles are 128 (fp32) / 256 (bf16) points: partial tiles must be masked."""
+    """Tiles are 128 (fp32) / 256 (16-bit) points: partial tiles must be masked.  The output goes into
+    a sentinel-padded buffer through the C ABI: rows >= P must come back untouched."""
+    from nerf_simple_amd import _lib
+    lib = _lib.lib()
     sd = synthetic.synthetic_state_dict(0, "structured")
     v = synthetic.points_in_scene(P, seed=P)
     with torch.no_grad():
         want = oracle.nerf_forward(sd, v).numpy()
-    for precision, tol in (("fp32", F32_TOL), ("bf16", BF16_TOL), ("fp16", FP16_TOL)):
+    vd = v.to(dev).contiguous()
+    for precision in ("fp32", "bf16", "fp16"):
         net = make_net(synthetic, dev, "structured", precision)
-        guard = torch.full((P + 64, 4), 777.0, device=dev)
-        with torch.no_grad():
-            out = net.forward(v.to(dev))
-        assert scaled_err(out.cpu().numpy(), want) <= tol
-        del guard
+        code = _lib.precision_code(precision)
+        out = torch.full((P + 300, 4), 777.0, device=dev)
+        _lib.check(lib.nerf_amd_mlp_forward(_lib.ptr(vd), _lib.ptr(net.packed_weights(code)), _lib.ptr(out), P, code,
+                                            _lib.stream_ptr(dev)), "nerf_amd_mlp_forward")
+        torch.cuda.synchronize()
+        assert scaled_err(out[:P].cpu().numpy(), want) <= TOL[(precision, "structured")]
+        assert bool((out[P:] == 777.0).all()), (precision, P, "wrote past the last point")
     with torch.no_grad():
         assert make_net(synthetic, dev, "default").forward(torch.zeros(0, 6, device=dev)).shape == (0, 4)
+
+
+@pytest.mark.parametrize("kind", ["default", "structured"])
+def test_mlp_hidden_activations_golden(dev, golden, synthetic, kind):
+    """Layer-by-layer: G2's intermediates h5 (after layers_0), h8 (after layers_1) and h9 (layers_2,
+    linear) against the activations the bf16 training forward saves (point-blocked layout of
+    csrc/nerf_layout.h, internal layers 4, 7 and 8), so an error is attributed to a layer instead of
+    showing up only in rgb / sigma.  bf16 storage: half an ulp is 2^-9 relative on top of the
+    accumulated operand rounding (observed <= 6e-3 / 1.2e-2 of the tensor's scale)."""
+    from nerf_simple_amd import _lib
+    lib = _lib.lib()
+    g = golden(f"mlp_{kind}.npz")
+    v = t(g["v"]).to(dev).contiguous()
+    P = v.shape[0]
+    net = make_net(synthetic, dev, kind, "bf16")
+    nb = int(lib.nerf_amd_train_activation_bytes(P))
+    acts = torch.zeros(nb, dtype=torch.uint8, device=dev)
+    out = torch.empty(P, 4, device=dev)
+    _lib.check(lib.nerf_amd_mlp_forward_train_points(_lib.ptr(v), _lib.ptr(net.packed_weights(_lib.BF16)), _lib.ptr(out),
+                                                     _lib.ptr(acts), P, _lib.stream_ptr(dev)), "forward_train_points")
+    torch.cuda.synchronize()
+    host = acts.cpu().numpy()
+    ntiles = (P + 255) // 256
+    bound = {"default": 1.5e-2, "structured": 3e-2}[kind]
+    for name, L in (("h5", 4), ("h8", 7), ("h9", 8)):
+        blk = host[L * ntiles * 131072:(L + 1) * ntiles * 131072].view(np.uint16).reshape(ntiles, 32, 256, 8)
+        a = blk.transpose(0, 2, 1, 3).reshape(ntiles * 256, 256)[:P]
+        got = torch.from_numpy(a.astype(np.int32) << 16).view(torch.float32).numpy()
+        err = scaled_err(got, g[name])
+        print(f"{kind} {name}: {err:.3e}")
+        assert err <= bound, (name, err)
+    assert scaled_err(out.cpu().numpy(), g["out"]) <= TOL[("bf16", kind)]
 
 
 def test_mlp_repack_after_update(dev, oracle, synthetic):
@@ -186,8 +226,9 @@ def test_composite_odd_sizes(dev, oracle):
 
 # ---------------------------------------------------------------- render_nerf
 @pytest.mark.parametrize("kind", ["default", "structured"])
-@pytest.mark.parametrize("precision,tol", [("fp32", F32_TOL), ("bf16", BF16_TOL), ("fp16", FP16_TOL)])
-def test_render_golden(dev, golden, synthetic, kind, precision, tol):
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+def test_render_golden(dev, golden, synthetic, kind, precision):
+    tol = TOL[(precision, kind)]
     from nerf_simple_amd.utils.rendering import render_nerf, render_rays
     assert render_rays is render_nerf
     g = golden(f"render_{kind}.npz")
@@ -376,14 +417,17 @@ def test_image_golden_fp32(dev, golden, synthetic, kind):
 
 
 # (kind, precision) -> (max |PSNR(GPU,T) - PSNR(CPU,T)| dB, min PSNR(GPU,CPU) dB)
-# BASELINE's criterion is 0.05 dB.  fp16 (same MFMA rate) and fp32 meet it on both weight
-# sets; bf16 meets it at trained-model-like weight
-# scale ("default") and misses it on the "structured" stress set, whose head
-# gains (sigma x8) amplify the 8-bit-mantissa rounding of weights and
-# activations ~10x (DESIGN.md section 6 quantifies the sources).
-PSNR_BOUNDS = {("default", "bf16"): (0.05, 55.0), ("structured", "bf16"): (0.30, 45.0),
-               ("default", "fp16"): (0.05, 75.0), ("structured", "fp16"): (0.05, 58.0),
-               ("default", "fp32"): (0.01, 90.0), ("structured", "fp32"): (0.01, 80.0)}
+# BASELINE's criterion is 0.05 dB.  fp32 and fp16 (the default render precision) meet it on both weight
+# sets.  bf16 meets it at nn.Linear weight scale ("default": 0.044 dB observed) and measures 0.21 dB
+# on the "structured" stress set; its bound there is the observed value + 20 %, NOT the criterion.
+# Why bf16 cannot meet it (tests/studies/precision_study.py): the error that
+# moves PSNR is the rounding of the WEIGHTS (a systematic perturbation of the network, correlated by
+# chance with any other low-dimensional perturbation such as the teacher's), every layer contributes
+# +-0.05..0.1 dB with either sign, and no subset of layers in fp16 short of all of them keeps three
+# test views inside 0.05 dB.  fp16 operands cost 5.0 % of throughput (clock) against bf16.
+PSNR_BOUNDS = {("default", "bf16"): (0.05, 66.0), ("structured", "bf16"): (0.25, 46.0),
+               ("default", "fp16"): (0.05, 84.0), ("structured", "fp16"): (0.05, 63.0),
+               ("default", "fp32"): (0.01, 130.0), ("structured", "fp32"): (0.01, 100.0)}
 
 
 @pytest.mark.parametrize("kind,precision", sorted(PSNR_BOUNDS))
@@ -443,7 +487,7 @@ def test_precision_override(dev, golden, synthetic):
         v = t(golden("mlp_structured.npz")["v"]).to(dev)
         o32 = net.forward(v, precision="fp32")
     assert scaled_err(a[0].cpu().numpy(), g["N64_rgb"]) <= F32_TOL
-    assert F32_TOL < scaled_err(b[0].cpu().numpy(), g["N64_rgb"]) <= BF16_TOL
+    assert F32_TOL < scaled_err(b[0].cpu().numpy(), g["N64_rgb"]) <= TOL[("bf16", "structured")]
     assert scaled_err(o32.cpu().numpy(), golden("mlp_structured.npz")["out"]) <= F32_TOL
 
 
@@ -683,39 +727,41 @@ def test_reference_rand_host_fallback(dev, monkeypatch):
         torch.set_rng_state(saved)
 
 
-def test_render_hierarchical_view_vs_oracle(dev, oracle, synthetic):
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_render_hierarchical_view_equals_composition(dev, oracle, synthetic, precision):
     """Config 4 as ONE library call (nerf_amd_render_hierarchical_forward: device rays -> coarse ->
-    sample_pdf -> fine -> clipped pixels) against the oracle's composition of the same stages on the
-    CPU (parity UNPINNED for the sampler: the reference has none; both render passes are render_nerf)."""
+    sample_pdf -> fine -> clipped pixels) == the stage-by-stage composition render_hierarchical on
+    host-generated rays, BIT for bit: the coarse weights of the fused kernel equal the two-launch
+    ones, so the sampler sees the same cdf and the fine pass the same positions.  The composition
+    itself is checked against the oracle in test_render_hierarchical (fp32: a random high-frequency
+    field turns a 1e-4 shift of a sample into another colour, so 16-bit coarse weights cannot be
+    compared with the CPU pixel by pixel).  Parity of the sampler is UNPINNED (not in the reference)."""
     from nerf_simple_amd.utils.nets import Nerf
-    from nerf_simple_amd.utils.rendering import render_hierarchical_view
+    from nerf_simple_amd.utils.rendering import render_hierarchical_view, render_hierarchical, generate_rays
     sd_c = synthetic.synthetic_state_dict(0, "structured")
     sd_f = synthetic.synthetic_state_dict(7, "structured")
-    H = W = 12
+    H, W = 12, 14
     cam = [H, W, synthetic.focal_from_fov(W)]
-    pose = torch.from_numpy(oracle.spherical_to_pose(4, -30, 15)).float()
-    rays = oracle.camera_rays(pose, cam)
+    pose = oracle.spherical_to_pose(4, -30, 15)
     gen = torch.Generator().manual_seed(8)
-    u_c, u_f = torch.rand(H * W, 64, generator=gen), torch.rand(H * W, 128, generator=gen)
-    with torch.no_grad():
-        wf, _, _ = oracle.render_hierarchical(rays, sd_c, sd_f, 64, 128, u_c, u_f)
-    want_rgb, want_disp = torch.clip(wf[0], 0, 1).numpy(), wf[1].numpy()
-    nc, nf = Nerf(precision="fp16").to(dev), Nerf(precision="fp16").to(dev)
+    u_c, u_f = torch.rand(H * W, 64, generator=gen).to(dev), torch.rand(H * W, 128, generator=gen).to(dev)
+    nc, nf = Nerf(precision=precision).to(dev), Nerf(precision=precision).to(dev)
     nc.load_state_dict(sd_c)
     nf.load_state_dict(sd_f)
     with torch.no_grad():
-        px = render_hierarchical_view(nc, nf, pose.numpy(), cam, 64, 128, u_c=u_c.to(dev), u_f=u_f.to(dev))
-        a = render_hierarchical_view(nc, nf, pose.numpy(), cam, 64, 128, u_c=u_c[:50].to(dev), u_f=u_f[:50].to(dev),
-                                     ray0=0, n_rays=50)
-        b = render_hierarchical_view(nc, nf, pose.numpy(), cam, 64, 128, u_c=u_c[50:].to(dev), u_f=u_f[50:].to(dev), ray0=50)
+        px = render_hierarchical_view(nc, nf, pose, cam, 64, 128, u_c=u_c, u_f=u_f)
+        a = render_hierarchical_view(nc, nf, pose, cam, 64, 128, u_c=u_c[:50], u_f=u_f[:50], ray0=0, n_rays=50)
+        b = render_hierarchical_view(nc, nf, pose, cam, 64, 128, u_c=u_c[50:], u_f=u_f[50:], ray0=50)
+        rays = generate_rays(pose, cam, dev)
+        fine, coarse, ts_f = render_hierarchical(rays, nc, nf, 64, 128, u_c=u_c, u_f=u_f)
+        dr = render_hierarchical_view(nc, nf, pose, cam, 64, 128, device_rng=True, seed=3)
+        dr2 = render_hierarchical(rays, nc, nf, 64, 128, device_rng=True, seed=3)[0]
     assert px.shape == (H * W, 4) and torch.equal(torch.cat([a, b]), px)
-    # fp16 coarse weights move the inverse-cdf samples slightly; the fine render sees slightly other positions
-    err_rgb = scaled_err(px[:, :3].cpu().numpy(), want_rgb)
-    err_disp = scaled_err(px[:, 3].cpu().numpy(), want_disp)
-    print(f"hierarchical one-call vs oracle: rgb {err_rgb:.2e} disp {err_disp:.2e}")
-    assert err_rgb <= 1.5e-2 and err_disp <= 1.5e-2
+    assert torch.equal(px[:, :3], torch.clip(fine[0], 0, 1)) and torch.equal(px[:, 3], fine[1])
+    assert torch.equal(dr[:, :3], torch.clip(dr2[0], 0, 1)) and torch.equal(dr[:, 3], dr2[1])
+    assert (ts_f[:, 1:] >= ts_f[:, :-1]).all() and torch.isfinite(px).all()
     # fp32 is not served by the one-call form
     n32 = Nerf(precision="fp32").to(dev)
     n32.load_state_dict(sd_c)
     with pytest.raises(RuntimeError, match="unsupported"):
-        render_hierarchical_view(n32, n32, pose.numpy(), cam, 64, 128, device_rng=True)
+        render_hierarchical_view(n32, n32, pose, cam, 64, 128, device_rng=True)
