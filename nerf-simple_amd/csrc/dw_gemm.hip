@@ -313,6 +313,17 @@ __global__ __launch_bounds__(256) void pack_draw_kernel(const float* __restrict_
     }
 }
 
+// Zero fill as a KERNEL.  hipMemsetAsync here becomes a memset node when the step is captured into a
+// hipGraph, and on ROCm 7.2 the float atomics of the kernels behind that node (executed at the memory
+// side) were seen to land on the buffer's OLD contents: gradients of 1e22..1e33 from the fourth
+// GraphedTrainStep of a process on, whenever the allocation had a previous tenant (eager launches and
+// fresh allocations were fine).  A kernel node orders like every other kernel -> kernel edge.
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, long long n) {
+    const long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < n) *reinterpret_cast<f32x4*>(p + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    else for (long long k = i; k < n; ++k) p[k] = 0.f;
+}
+
 }  // namespace
 
 // grads: flat fp32 [595844] in state_dict order (zeroed here); scratch: P*64 bytes (dsr)
@@ -320,7 +331,10 @@ extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* a
                                                const void* posx64_v, const void* posd32_v, void* scratch,
                                                float* grads, long long P, hipStream_t stream) {
     (void)hipGetLastError();
-    hipError_t e = hipMemsetAsync(grads, 0, sizeof(float) * PARAM_COUNT, stream);
+    static_assert(PARAM_COUNT % 4 == 0, "16-byte zero fill");
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((PARAM_COUNT / 4 + 255) / 256), dim3(256), 0, stream, grads,
+                       (long long)PARAM_COUNT);
+    hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (P <= 0) return 0;
     const __bf16* acts = reinterpret_cast<const __bf16*>(acts_v);

@@ -155,7 +155,8 @@ def test_mlp_hidden_activations_golden(dev, golden, synthetic, kind):
         blk = host[L * ntiles * 131072:(L + 1) * ntiles * 131072].view(np.uint16).reshape(ntiles, 32, 256, 8)
         a = blk.transpose(0, 2, 1, 3).reshape(ntiles * 256, 256)[:P]
         got = torch.from_numpy(a.astype(np.int32) << 16).view(torch.float32).numpy()
-        err = scaled_err(got, g[name])
+        want = g[name]                                   # the fixture keeps the intermediates of its first rows
+        err = scaled_err(got[:want.shape[0]], want)
         print(f"{kind} {name}: {err:.3e}")
         assert err <= bound, (name, err)
     assert scaled_err(out.cpu().numpy(), g["out"]) <= TOL[("bf16", kind)]
