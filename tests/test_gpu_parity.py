@@ -135,7 +135,7 @@ def test_mlp_hidden_activations_golden(dev, golden, synthetic, kind):
     linear) against the activations the bf16 training forward saves (point-blocked layout of
     csrc/nerf_layout.h, internal layers 4, 7 and 8), so an error is attributed to a layer instead of
     showing up only in rgb / sigma.  bf16 storage: half an ulp is 2^-9 relative on top of the
-    accumulated operand rounding (observed <= 6e-3 / 1.2e-2 of the tensor's scale)."""
+    accumulated operand rounding (observed <= 1.0e-3 / 8.2e-3 of the tensor's scale)."""
     from nerf_simple_amd import _lib
     lib = _lib.lib()
     g = golden(f"mlp_{kind}.npz")
@@ -150,7 +150,7 @@ def test_mlp_hidden_activations_golden(dev, golden, synthetic, kind):
     torch.cuda.synchronize()
     host = acts.cpu().numpy()
     ntiles = (P + 255) // 256
-    bound = {"default": 1.5e-2, "structured": 3e-2}[kind]
+    bound = {"default": 3e-3, "structured": 2.5e-2}[kind]
     for name, L in (("h5", 4), ("h8", 7), ("h9", 8)):
         blk = host[L * ntiles * 131072:(L + 1) * ntiles * 131072].view(np.uint16).reshape(ntiles, 32, 256, 8)
         a = blk.transpose(0, 2, 1, 3).reshape(ntiles * 256, 256)[:P]

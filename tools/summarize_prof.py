@@ -1,39 +1,61 @@
 #!/usr/bin/env python3
-"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into one text summary."""
+"""Condense rocprofv3 CSV output (kernel stats + PMC passes) into one text summary and one JSON file.
+
+    summarize_prof.py <profile dir> [kernel-name substring ...]
+
+The JSON (<profile dir>/pmc.json; committed as profiles/<tag>_pmc.json) holds, per kernel whose name
+contains one of the substrings (default: nerf_mlp, dw_gemm, composite), the mean of every counter per
+dispatch and the kernel-trace durations; bench.py reads `traffic` out of it."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
 out = sys.argv[1]
+keys = sys.argv[2:] or ["nerf_mlp", "dw_gemm", "composite"]
 
 
 def find(sub, pat):
     return sorted(glob.glob(os.path.join(out, sub, "**", pat), recursive=True))
 
 
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "")[:70]
+
+
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for f in find("trace", "*kernel_stats.csv"):
     for i, row in enumerate(csv.reader(open(f))):
-        if i < 12:
-            print(", ".join(row))
+        if i < 14:
+            print(", ".join(c[:110] for c in row))
 print()
-print("== per-dispatch durations of the fused MLP kernel (kernel trace) ==")
+summary = {"source": os.path.basename(os.path.normpath(out)), "kernels": {}}
+print("== per-dispatch durations (kernel trace) ==")
+dur = defaultdict(list)
+meta = {}
 for f in find("trace", "*kernel_trace.csv"):
-    rows = list(csv.DictReader(open(f)))
-    for r in rows:
-        if "nerf_mlp" in r.get("Kernel_Name", ""):
-            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-            print(f'{r["Kernel_Name"][:60]:60s} {d:9.3f} ms  grid={r.get("Grid_Size","?")} wg={r.get("Workgroup_Size","?")} '
-                  f'vgpr={r.get("VGPR_Count","?")} agpr={r.get("Accum_VGPR_Count","?")} sgpr={r.get("SGPR_Count","?")} lds={r.get("LDS_Block_Size","?")}')
+    for r in csv.DictReader(open(f)):
+        n = r.get("Kernel_Name", "")
+        if any(k in n for k in keys):
+            dur[short(n)].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+            meta[short(n)] = {k: r.get(k, "?") for k in ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size")}
+for n, d in dur.items():
+    print(f"{n:70s} n={len(d)} mean={sum(d)/len(d):9.3f} ms min={min(d):9.3f} max={max(d):9.3f}  {meta[n]}")
+    summary["kernels"].setdefault(n, {})["duration_ms_mean"] = sum(d) / len(d)
+    summary["kernels"][n]["dispatches"] = len(d)
 print()
-print("== PMC counters, fused MLP kernel, mean per dispatch ==")
-for sub in ("pmc_sq", "pmc_sq2", "pmc_fetch", "pmc_write"):
-    acc = defaultdict(list)
+print("== PMC counters, mean per dispatch ==")
+for sub in sorted(os.path.basename(p) for p in glob.glob(os.path.join(out, "pmc_*")) if os.path.isdir(p)):
+    acc = defaultdict(lambda: defaultdict(list))
     for f in find(sub, "*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "nerf_mlp" in r.get("Kernel_Name", ""):
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, v in acc.items():
-        print(f"{sub:10s} {k:34s} mean={sum(v)/len(v):.6g}  n={len(v)}")
+            n = r.get("Kernel_Name", "")
+            if any(k in n for k in keys):
+                acc[short(n)][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for n, cs in acc.items():
+        for k, v in cs.items():
+            print(f"{sub:10s} {n:60s} {k:30s} mean={sum(v)/len(v):.6g}  n={len(v)}")
+            summary["kernels"].setdefault(n, {})[k] = sum(v) / len(v)
+json.dump(summary, open(os.path.join(out, "pmc.json"), "w"), indent=1)
