@@ -69,6 +69,8 @@ int      nerf_amd_layout_src_col(int precision, int layer, int kstep, int group,
  * the MFMA-fragment-ordered image the fused kernels stream.  Derived cache:
  * re-run after any parameter update.  */
 int nerf_amd_pack_weights(const float* params, void* packed, int precision, void* stream);
+/* The two images a training step needs (NERF_AMD_BF16 and NERF_AMD_BF16_BWD) in one launch. */
+int nerf_amd_pack_weights_train(const float* params, void* packed_bf16, void* packed_bwd, void* stream);
 
 /* ---- positional encoding: utils/xyz.py:6-36 --------------------------------- */
 /* gamma(x, L): x[n] -> out[n, 2L] = [sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)]
@@ -121,6 +123,14 @@ int nerf_amd_volume_render_rays_backward(const float* raw, const float* ts, cons
                                          const float* g_rgb, const float* g_disp, const float* g_alpha,
                                          const float* g_acc, const float* g_w,
                                          float* d_raw, int64_t B, int N, void* stream);
+
+/* Training form (reference train.py:51-54 between the MLP forward and its backward): compositing
+ * forward, loss = MSELoss(rgb, target) (mean over 3B elements), and the backward of both in ONE launch:
+ * raw, ts, rays, target[B,3] -> rgb[B,3] (may be NULL; feed it to nerf_amd_mse_loss for the loss value)
+ * and d_raw[B,N,4] = d loss / d raw.  N <= 512. */
+int nerf_amd_volume_render_mse_backward(const float* raw, const float* ts, const float* rays,
+                                        const float* target, float* rgb, float* d_raw,
+                                        int64_t B, int N, void* stream);
 
 /* ---- the whole path: render_nerf, utils/rendering.py:13-45 ------------------- */
 /* rays[B,6] = [origin, direction] -> (rgb[B,3], disp[B], alpha[B,N], acc[B], w[B,N]).
@@ -250,6 +260,13 @@ int64_t nerf_amd_param_gradients_scratch_bytes(int64_t P);
 int nerf_amd_param_gradients(const float* d_raw, const void* acts, const void* dys,
                              const void* posx64, const void* posd32, void* scratch,
                              float* grads, int64_t P, void* stream);
+
+/* The same in two parts, so a captured step can overlap the first with the dX chain (both need only
+ * d_raw): _begin zeroes `grads`, packs d_raw into `scratch` and adds the two head bias gradients;
+ * _finish runs the 14 products and the other bias sums. */
+int nerf_amd_param_gradients_begin(const float* d_raw, void* scratch, float* grads, int64_t P, void* stream);
+int nerf_amd_param_gradients_finish(const void* acts, const void* dys, const void* posx64, const void* posd32,
+                                    const void* scratch, float* grads, int64_t P, void* stream);
 
 /* ---- loss: nn.MSELoss(), reference train.py:42,52 -------------------------------- */
 /* loss[0] = mean((pred - target)^2) over n elements; g_pred[n] (may be NULL) =

@@ -47,6 +47,10 @@ _SIGNATURES = {
     "nerf_amd_volume_render_backward": (_i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_volume_render_rays": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_volume_render_rays_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_volume_render_mse_backward": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_param_gradients_begin": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "nerf_amd_param_gradients_finish": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
+    "nerf_amd_pack_weights_train": (_i32, [_vp, _vp, _vp, _vp]),
     "nerf_amd_mse_loss": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "nerf_amd_mlp_forward_train_points": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "nerf_amd_encode_points_bf16": (_i32, [_vp, _vp, _vp, _i64, _vp]),

@@ -9,6 +9,12 @@ using namespace nerf_layout;
 
 extern "C" {
 int nerf_amd_launch_pack(const float*, void*, int, hipStream_t);
+int nerf_amd_launch_pack_train(const float*, void*, void*, hipStream_t);
+int nerf_amd_launch_composite_mse_backward(const float*, const float*, const float*, const float*, float*, float*, long long,
+                                           int, hipStream_t);
+int nerf_amd_launch_param_gradients_begin(const float*, void*, float*, long long, hipStream_t);
+int nerf_amd_launch_param_gradients_finish(const void*, const void*, const void*, const void*, const void*, float*, long long,
+                                           hipStream_t);
 int nerf_amd_launch_gamma(const float*, long long, float*, long long, int, hipStream_t);
 int nerf_amd_launch_posenc(const float*, float*, float*, long long, int, int, hipStream_t);
 int nerf_amd_launch_composite(const float*, const float*, const float*, long long, float*, float*,
@@ -132,6 +138,11 @@ int nerf_amd_pack_weights(const float* params, void* packed, int precision, void
     return nerf_amd_launch_pack(params, packed, precision, S(stream));
 }
 
+int nerf_amd_pack_weights_train(const float* params, void* packed_bf16, void* packed_bwd, void* stream) {
+    if (!params || !packed_bf16 || !packed_bwd) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_pack_train(params, packed_bf16, packed_bwd, S(stream));
+}
+
 int nerf_amd_gamma(const float* x, int64_t x_stride, float* out, int64_t n, int L, void* stream) {
     if (n < 0 || L < 0 || x_stride < 0) return NERF_AMD_EINVAL;
     if (n == 0 || L == 0) return 0;
@@ -192,6 +203,15 @@ int nerf_amd_volume_render_rays_backward(const float* raw, const float* ts, cons
     if (!raw || !ts || !rays || !d_raw) return NERF_AMD_EINVAL;
     return nerf_amd_launch_composite_backward(raw, ts, rays + 3, 6, g_rgb, g_disp, g_alpha, g_acc, g_w, d_raw, B, N, 1,
                                               S(stream));
+}
+
+int nerf_amd_volume_render_mse_backward(const float* raw, const float* ts, const float* rays, const float* target,
+                                       float* rgb, float* d_raw, int64_t B, int N, void* stream) {
+    if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (N > 512) return NERF_AMD_EUNSUP;
+    if (!raw || !ts || !rays || !target || !d_raw) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_composite_mse_backward(raw, ts, rays, target, rgb, d_raw, B, N, S(stream));
 }
 
 int nerf_amd_mse_loss(const float* pred, const float* target, float* loss, float* g_pred, int64_t n, void* stream) {
@@ -434,6 +454,19 @@ int nerf_amd_param_gradients(const float* d_raw, const void* acts, const void* d
     if (P < 0 || !grads) return NERF_AMD_EINVAL;
     if (P > 0 && (!d_raw || !acts || !dys || !posx64 || !posd32 || !scratch)) return NERF_AMD_EINVAL;
     return nerf_amd_launch_param_gradients(d_raw, acts, dys, posx64, posd32, scratch, grads, P, S(stream));
+}
+
+int nerf_amd_param_gradients_begin(const float* d_raw, void* scratch, float* grads, int64_t P, void* stream) {
+    if (P < 0 || !grads) return NERF_AMD_EINVAL;
+    if (P > 0 && (!d_raw || !scratch)) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_param_gradients_begin(d_raw, scratch, grads, P, S(stream));
+}
+
+int nerf_amd_param_gradients_finish(const void* acts, const void* dys, const void* posx64, const void* posd32,
+                                    const void* scratch, float* grads, int64_t P, void* stream) {
+    if (P < 0 || !grads) return NERF_AMD_EINVAL;
+    if (P > 0 && (!acts || !dys || !posx64 || !posd32 || !scratch)) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_param_gradients_finish(acts, dys, posx64, posd32, scratch, grads, P, S(stream));
 }
 
 int nerf_amd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

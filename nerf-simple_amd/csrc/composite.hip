@@ -70,7 +70,8 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_backward_kernel
     const float* __restrict__ raw, const float* __restrict__ ts, const float* __restrict__ dirs,
     long long dirs_stride, const float* __restrict__ g_rgb, const float* __restrict__ g_disp,
     const float* __restrict__ g_alpha, const float* __restrict__ g_acc, const float* __restrict__ g_w,
-    float* __restrict__ d_raw, long long B, int N, int normalize_dirs) {
+    float* __restrict__ d_raw, long long B, int N, int normalize_dirs,
+    const float* __restrict__ mse_target, float* __restrict__ rgb_out, float mse_scale) {
     const long long ray = (long long)blockIdx.x * RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= B) return;
     const int lane = threadIdx.x & 63;
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_backward_kernel
     float al[MAX_CHUNKS], Tt[MAX_CHUNKS], fc[MAX_CHUNKS], ds[MAX_CHUNKS], tt[MAX_CHUNKS];
     f32x4 cc[MAX_CHUNKS];
     float carry = 1.0f, depth = 0.f, accw = 0.f;
+    float sr = 0.f, sg = 0.f, sb = 0.f;            // training form: the forward's rgb, for the loss gradient
 #pragma unroll
     for (int ch = 0; ch < MAX_CHUNKS; ++ch) {
         const int base = ch * 64;
@@ -121,14 +123,27 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_backward_kernel
             if (lane == 0) excl = 1.0f;
             al[ch] = a; fc[ch] = fac; Tt[ch] = carry * excl;
             carry *= __shfl(incl, 63);
-            if (valid) { depth += a * Tt[ch] * tt[ch]; accw += a * Tt[ch]; }
+            if (valid) {
+                depth += a * Tt[ch] * tt[ch]; accw += a * Tt[ch];
+                // the same ops as the forward compositor (composite_device.h), so rgb_out equals its rgb
+                const float wt = __fmul_rn(a, Tt[ch]);
+                sr = __fmaf_rn(wt, cc[ch][0], sr); sg = __fmaf_rn(wt, cc[ch][1], sg); sb = __fmaf_rn(wt, cc[ch][2], sb);
+            }
         }
     }
     depth = wave_sum(depth); accw = wave_sum(accw);
 
     // upstream gradients that reach every w_i of the ray
-    const float gr = g_rgb ? g_rgb[ray * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f,
-                gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+    float gr = g_rgb ? g_rgb[ray * 3 + 0] : 0.f, gg = g_rgb ? g_rgb[ray * 3 + 1] : 0.f,
+          gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
+    if (mse_target) {
+        // loss = MSELoss(rgb, target) (train.py:52): d loss / d rgb = 2 (rgb - target) / (3 B), formed here
+        sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb);
+        gr = 2.0f * (sr - mse_target[ray * 3 + 0]) * mse_scale;
+        gg = 2.0f * (sg - mse_target[ray * 3 + 1]) * mse_scale;
+        gb = 2.0f * (sb - mse_target[ray * 3 + 2]) * mse_scale;
+        if (rgb_out && lane == 0) { rgb_out[ray * 3 + 0] = sr; rgb_out[ray * 3 + 1] = sg; rgb_out[ray * 3 + 2] = sb; }
+    }
     float gdep = 0.f, gac = g_acc ? g_acc[ray] : 0.f;
     if (g_disp) {
         const float q = depth / accw;
@@ -200,7 +215,21 @@ extern "C" int nerf_amd_launch_composite_backward(const float* raw, const float*
     const long long blocks = (B + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
     hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_BLOCK), 0, stream,
                        raw, ts, dirs, dirs_stride, g_rgb, g_disp, g_alpha, g_acc, g_w, d_raw, B, N,
-                       normalize_dirs);
+                       normalize_dirs, nullptr, nullptr, 0.f);
+    return (int)hipGetLastError();
+}
+
+// training form: compositing forward + MSELoss gradient + compositing backward in one launch
+extern "C" int nerf_amd_launch_composite_mse_backward(const float* raw, const float* ts, const float* rays,
+                                                      const float* target, float* rgb, float* d_raw, long long B,
+                                                      int N, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (B == 0) return 0;
+    if (N > 64 * MAX_CHUNKS) return -2;
+    const long long blocks = (B + RAYS_PER_BLOCK - 1) / RAYS_PER_BLOCK;
+    hipLaunchKernelGGL(composite_backward_kernel, dim3((unsigned)blocks), dim3(64 * RAYS_PER_BLOCK), 0, stream,
+                       raw, ts, rays + 3, 6ll, nullptr, nullptr, nullptr, nullptr, nullptr, d_raw, B, N, 1,
+                       target, rgb, 1.0f / (3.0f * (float)B));
     return (int)hipGetLastError();
 }
 

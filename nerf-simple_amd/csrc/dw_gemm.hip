@@ -326,10 +326,12 @@ __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, lo
 
 }  // namespace
 
-// grads: flat fp32 [595844] in state_dict order (zeroed here); scratch: P*64 bytes (dsr)
-extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* acts_v, const void* dys_v,
-                                               const void* posx64_v, const void* posd32_v, void* scratch,
-                                               float* grads, long long P, hipStream_t stream) {
+// grads: flat fp32 [595844] in state_dict order (zeroed here); scratch: P*64 bytes (dsr).
+// begin: zero the gradient vector, pack d_raw for the two head products, head bias gradients.
+// finish: the 14 split-K products + the other bias gradients.  (Two entry points so a captured step can
+// run `begin` on a side branch beside the dX chain, which needs d_raw as well.)
+extern "C" int nerf_amd_launch_param_gradients_begin(const float* d_raw, void* scratch, float* grads, long long P,
+                                                     hipStream_t stream) {
     (void)hipGetLastError();
     static_assert(PARAM_COUNT % 4 == 0, "16-byte zero fill");
     hipLaunchKernelGGL(zero_f32_kernel, dim3((PARAM_COUNT / 4 + 255) / 256), dim3(256), 0, stream, grads,
@@ -337,18 +339,26 @@ extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* a
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     if (P <= 0) return 0;
+    hipLaunchKernelGGL(pack_draw_kernel, dim3(512), dim3(256), 0, stream, d_raw, reinterpret_cast<__bf16*>(scratch), P,
+                       grads + OFF_C1_B, grads + OFF_SIG_B);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nerf_amd_launch_param_gradients_finish(const void* acts_v, const void* dys_v, const void* posx64_v,
+                                                      const void* posd32_v, const void* scratch, float* grads,
+                                                      long long P, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipError_t e = hipSuccess;
+    if (P <= 0) return 0;
     const __bf16* acts = reinterpret_cast<const __bf16*>(acts_v);
     const __bf16* dys = reinterpret_cast<const __bf16*>(dys_v);
     const __bf16* posx = reinterpret_cast<const __bf16*>(posx64_v);
     const __bf16* posd = reinterpret_cast<const __bf16*>(posd32_v);
-    __bf16* dsr = reinterpret_cast<__bf16*>(scratch);
+    const __bf16* dsr = reinterpret_cast<const __bf16*>(scratch);
     // point-blocked activation layers (nerf_layout.h): layer L at L * act_layer_stride(P) bytes; leading dimension 0
     auto act = [&](int L) { return acts + act_offset_bytes(L, P) / 2; };
     auto dy = [&](int L) { return dys + act_offset_bytes(L, P) / 2; };
     constexpr int BLK = 0;
-
-    hipLaunchKernelGGL(pack_draw_kernel, dim3(512), dim3(256), 0, stream, d_raw, dsr, P, grads + OFF_C1_B,
-                       grads + OFF_SIG_B);
 
     GemmTable t{};
     t.P = P;
@@ -420,4 +430,12 @@ extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* a
     hipLaunchKernelGGL(dw_gemm_kernel, dim3(wg), dim3(512), LDS_BYTES, stream, t);
 
     return (int)hipGetLastError();
+}
+
+extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* acts_v, const void* dys_v,
+                                               const void* posx64_v, const void* posd32_v, void* scratch,
+                                               float* grads, long long P, hipStream_t stream) {
+    const int rc = nerf_amd_launch_param_gradients_begin(d_raw, scratch, grads, P, stream);
+    if (rc) return rc;
+    return nerf_amd_launch_param_gradients_finish(acts_v, dys_v, posx64_v, posd32_v, scratch, grads, P, stream);
 }

@@ -73,7 +73,49 @@ __global__ void pack_bias_kernel(const float* __restrict__ params, float* __rest
     }
 }
 
+// the three images of a training step in ONE launch: forward bf16 image, its bias table, backward image
+__global__ void pack_train_kernel(const float* __restrict__ params, __bf16* __restrict__ img, float* __restrict__ bias,
+                                  __bf16* __restrict__ bwd) {
+    const long long n_img = (long long)B16_WEIGHT_KIB * 512, n_bwd = (long long)BWD_WEIGHT_KIB * 512;
+    const long long total = n_img + n_bwd + F32_BIAS_FLOATS;
+    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
+         e += (long long)gridDim.x * blockDim.x) {
+        if (e < n_img) {
+            const int kib = (int)(e >> 9);
+            int L = 0;
+            while (L + 1 < NUM_LAYERS && kib >= b16_layer_off_kib(L + 1)) ++L;
+            const int rel = kib - b16_layer_off_kib(L);
+            const int rt = rel / b16_ks(L), s = rel % b16_ks(L);
+            const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
+            img[e] = (__bf16)weight_at(params, L, 16 * rt + (lane & 15), src_col_b16(L, s, lane >> 4, j));
+        } else if (e < n_img + n_bwd) {
+            const long long q = e - n_img;
+            const int kib = (int)(q >> 9);
+            int b = 0;
+            while (b + 1 < NUM_BWD && kib >= bwd_layer_off_kib(b + 1)) ++b;
+            const int rel = kib - bwd_layer_off_kib(b);
+            const int rt = rel / bwd_ks(b), s = rel % bwd_ks(b);
+            const int lane = (int)(q >> 3) & 63, j = (int)q & 7;
+            const int o = bwd_src_out(b, s, lane >> 4, j);
+            bwd[q] = (__bf16)(o < 0 ? 0.f : weight_at(params, bwd_desc(b).wl, o, 16 * rt + (lane & 15)));
+        } else {
+            const int q = (int)(e - n_img - n_bwd);
+            int L = 0;
+            while (L + 1 < NUM_LAYERS && q >= f32_bias_off(L + 1)) ++L;
+            bias[q] = bias_at(params, L, q - f32_bias_off(L));
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int nerf_amd_launch_pack_train(const float* params, void* packed_bf16, void* packed_bwd, hipStream_t stream) {
+    (void)hipGetLastError();
+    char* img = reinterpret_cast<char*>(packed_bf16);
+    hipLaunchKernelGGL(pack_train_kernel, dim3(2048), dim3(256), 0, stream, params, reinterpret_cast<__bf16*>(img),
+                       reinterpret_cast<float*>(img + (long long)B16_WEIGHT_KIB * 1024), reinterpret_cast<__bf16*>(packed_bwd));
+    return (int)hipGetLastError();
+}
 
 extern "C" int nerf_amd_launch_pack(const float* params, void* packed, int precision, hipStream_t stream) {
     (void)hipGetLastError();   // drop any stale error: the return value is about THIS launch

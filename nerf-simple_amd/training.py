@@ -112,6 +112,11 @@ def volume_render_autograd(nerf_outs, ts, dirs):
 # --------------------------------------------------------------------------
 # fused dense layers: HIP forward (saving activations) + HIP dX chain + HIP dW
 # --------------------------------------------------------------------------
+def ctypes_stream(stream):
+    import ctypes
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
 def _check_trainable(precision):
     if _lib.precision_code(precision) == _lib.F32:
         raise RuntimeError("fp32 training is not supported (NERF_AMD_EUNSUP): the training kernels are bf16; "
@@ -270,11 +275,12 @@ class GraphedTrainStep:
     """``train_step`` (reference train.py:47-57) for the fused bf16 path with every buffer
     allocated once and the launches captured into hipGraphs that are replayed per iteration:
 
-        graph A: forward (saving activations) -> encoder rows -> compositor -> MSE loss and its
-                 gradient -> compositor backward -> dX chain -> all 24 parameter gradients
-                 (8 launches + one memset, all through the C ABI: no torch kernels)
+        graph A: forward (saving activations) -> compositor + MSE gradient + compositor backward (one
+                 kernel) -> dX chain -> all 24 parameter gradients, with the encoder rows, the loss
+                 value, the gradient zero fill and the d_raw pack on a parallel branch
+                 (9 kernel nodes, all through the C ABI: no torch kernels, no memset node)
         [one in-place all-reduce of the flat gradient vector when a process group is given]
-        graph B: Adam over the flat parameter vector -> re-pack the two MFMA weight images
+        graph B: Adam over the flat parameter vector -> re-pack the two MFMA weight images (one kernel)
 
     Step-dependent scalars do not live in kernel arguments: the jitter comes from the ``u``
     buffer (filled per call; default the reference's one ``torch.rand(B, N)`` draw from the CPU
@@ -312,9 +318,6 @@ class GraphedTrainStep:
         self.posx = torch.empty((P, 64), dtype=torch.bfloat16, device=dev)
         self.posd = torch.empty((P, 32), dtype=torch.bfloat16, device=dev)
         self.rgb = torch.empty((B, 3), **f32)
-        self.disp = torch.empty((B,), **f32)
-        self.acc = torch.empty((B,), **f32)
-        self.g_rgb = torch.empty((B, 3), **f32)
         self.d_raw = torch.empty((B, N_, 4), **f32)
         self.grads = torch.zeros(int(lib.nerf_amd_param_count()), **f32)
         self.scratch = torch.empty(max(int(lib.nerf_amd_param_gradients_scratch_bytes(P)), 16), dtype=torch.uint8,
@@ -322,6 +325,7 @@ class GraphedTrainStep:
         self.loss = torch.zeros((), **f32)
         self.hyper = torch.zeros(6, **f32)
         self._ring = _HyperRing()
+        self._side = torch.cuda.Stream(dev)
         # parameters' .grad are views of the flat gradient vector, as after the eager fused backward
         off = 0
         for p in optimizer.params:
@@ -332,30 +336,37 @@ class GraphedTrainStep:
 
     # ---- the two launch sequences --------------------------------------------------
     def _forward_backward(self):
+        """Main branch: forward -> compositing + MSE gradient + compositing backward -> dX chain -> dW.
+        Side branch (a fork / join inside the captured graph): the encoder rows of the dW products
+        beside the forward, then loss value + gradient-vector zero fill + d_raw pack beside the dX chain."""
         lib, B, N_, P = _lib.lib(), self.B, self.N, self.B * self.N
-        st = _lib.stream_ptr(self.dev)
         packed = self.net.packed_weights(_lib.BF16)
         image = self.net.packed_weights(_lib.BF16_BWD)
         ck, ptr = _lib.check, _lib.ptr
+        main = torch.cuda.current_stream(self.dev)
+        side = self._side
+        st, ss = ctypes_stream(main), ctypes_stream(side)
+        side.wait_stream(main)
+        # same sample positions as the forward draws them: ts = f(u) bit for bit (flags 0, the same u / tbins)
+        ck(lib.nerf_amd_sample_encode_bf16(ptr(self.rays), ptr(self.u), ptr(self.tbins), 0, 0, 0,
+                                           ptr(self.posx), ptr(self.posd), None, B, N_, ss),
+           "nerf_amd_sample_encode_bf16")
         ck(lib.nerf_amd_mlp_forward_train(ptr(self.rays), ptr(self.u), ptr(self.tbins), ptr(packed), 0, 0, 0,
                                           ptr(self.raw), ptr(self.ts), ptr(self.acts), B, N_, st),
            "nerf_amd_mlp_forward_train")
-        ck(lib.nerf_amd_sample_encode_bf16(ptr(self.rays), ptr(self.ts), None, _lib.FLAG_TS_GIVEN, 0, 0,
-                                           ptr(self.posx), ptr(self.posd), None, B, N_, st),
-           "nerf_amd_sample_encode_bf16")
-        # only rgb feeds the loss (train.py:52): alpha / w are not materialised
-        ck(lib.nerf_amd_volume_render_rays(ptr(self.raw), ptr(self.ts), ptr(self.rays), ptr(self.rgb), ptr(self.disp),
-                                           None, ptr(self.acc), None, B, N_, st), "nerf_amd_volume_render_rays")
-        ck(lib.nerf_amd_mse_loss(ptr(self.rgb), ptr(self.gt), ptr(self.loss), ptr(self.g_rgb), B * 3, st),
-           "nerf_amd_mse_loss")
-        ck(lib.nerf_amd_volume_render_rays_backward(ptr(self.raw), ptr(self.ts), ptr(self.rays), ptr(self.g_rgb), None,
-                                                    None, None, None, ptr(self.d_raw), B, N_, st),
-           "nerf_amd_volume_render_rays_backward")
+        # only rgb feeds the loss (train.py:52): disparity, alpha, acc, w are not materialised
+        ck(lib.nerf_amd_volume_render_mse_backward(ptr(self.raw), ptr(self.ts), ptr(self.rays), ptr(self.gt), ptr(self.rgb),
+                                                   ptr(self.d_raw), B, N_, st), "nerf_amd_volume_render_mse_backward")
+        side.wait_stream(main)
+        ck(lib.nerf_amd_mse_loss(ptr(self.rgb), ptr(self.gt), ptr(self.loss), None, B * 3, ss), "nerf_amd_mse_loss")
+        ck(lib.nerf_amd_param_gradients_begin(ptr(self.d_raw), ptr(self.scratch), ptr(self.grads), P, ss),
+           "nerf_amd_param_gradients_begin")
         ck(lib.nerf_amd_mlp_backward(ptr(self.d_raw), ptr(image), ptr(self.acts), ptr(self.dys), P, st),
            "nerf_amd_mlp_backward")
-        ck(lib.nerf_amd_param_gradients(ptr(self.d_raw), ptr(self.acts), ptr(self.dys), ptr(self.posx),
-                                        ptr(self.posd), ptr(self.scratch), ptr(self.grads), P, st),
-           "nerf_amd_param_gradients")
+        main.wait_stream(side)
+        ck(lib.nerf_amd_param_gradients_finish(ptr(self.acts), ptr(self.dys), ptr(self.posx), ptr(self.posd),
+                                               ptr(self.scratch), ptr(self.grads), P, st),
+           "nerf_amd_param_gradients_finish")
 
     def _update(self):
         lib, opt = _lib.lib(), self.opt

@@ -98,6 +98,14 @@ class Nerf(nn.Module):
         stamp = tuple((p.data_ptr(), p._version) for p in self._param_list())
         codes = {code for (d, code) in self._packed if d == dev} or {_lib.precision_code(self.precision)}
         with torch.cuda.device(dev):
+            if _lib.BF16 in codes and _lib.BF16_BWD in codes:
+                # the training pair in one launch
+                a, b = self._packed[(dev, _lib.BF16)][1], self._packed[(dev, _lib.BF16_BWD)][1]
+                _lib.check(lib.nerf_amd_pack_weights_train(_lib.ptr(flat), _lib.ptr(a), _lib.ptr(b), _lib.stream_ptr(dev)),
+                           "nerf_amd_pack_weights_train")
+                self._packed[(dev, _lib.BF16)] = (stamp, a)
+                self._packed[(dev, _lib.BF16_BWD)] = (stamp, b)
+                codes = codes - {_lib.BF16, _lib.BF16_BWD}
             for code in codes:
                 hit = self._packed.get((dev, code))
                 packed = hit[1] if hit is not None else torch.empty(

@@ -104,6 +104,43 @@ def _compare_with_oracle(oracle, synthetic, kind, rays, gt, u, N, loss, grads, t
     return want
 
 
+def test_fused_train_compositor_and_pack(dev, synthetic):
+    """The training-step conveniences against the entry points they merge: compositing + MSE gradient +
+    compositing backward in one launch == volume_render_rays -> mse_loss -> volume_render_rays_backward
+    (rgb bit-equal, d_raw to rounding), and the one-launch training re-pack == the two separate packs."""
+    from nerf_simple_amd import _lib
+    lib = _lib.lib()
+    st = _lib.stream_ptr(dev)
+    gen = torch.Generator().manual_seed(77)
+    for B, N in ((64, 64), (33, 100), (5, 300)):
+        raw = torch.randn(B, N, 4, generator=gen).to(dev)
+        ts = torch.sort(torch.rand(B, N, generator=gen) * 4 + 2, dim=1).values.to(dev)
+        rays = torch.randn(B, 6, generator=gen).to(dev)
+        gt = torch.rand(B, 3, generator=gen).to(dev)
+        rgb, disp, acc = torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
+        loss, g_rgb, d_ref = torch.zeros((), device=dev), torch.empty(B, 3, device=dev), torch.empty(B, N, 4, device=dev)
+        ck, ptr = _lib.check, _lib.ptr
+        ck(lib.nerf_amd_volume_render_rays(ptr(raw), ptr(ts), ptr(rays), ptr(rgb), ptr(disp), None, ptr(acc), None, B, N, st), "v")
+        ck(lib.nerf_amd_mse_loss(ptr(rgb), ptr(gt), ptr(loss), ptr(g_rgb), B * 3, st), "m")
+        ck(lib.nerf_amd_volume_render_rays_backward(ptr(raw), ptr(ts), ptr(rays), ptr(g_rgb), None, None, None, None,
+                                                    ptr(d_ref), B, N, st), "b")
+        rgb2, d2 = torch.empty(B, 3, device=dev), torch.empty(B, N, 4, device=dev)
+        ck(lib.nerf_amd_volume_render_mse_backward(ptr(raw), ptr(ts), ptr(rays), ptr(gt), ptr(rgb2), ptr(d2), B, N, st), "f")
+        torch.cuda.synchronize()
+        assert torch.equal(rgb2, rgb)
+        assert float((d2 - d_ref).abs().max()) <= 2e-6 * float(d_ref.abs().max()), (B, N)
+        assert abs(float(loss) - float(((rgb - gt) ** 2).mean())) <= 1e-6 * float(loss)
+    flat = synthetic.flatten_state_dict(synthetic.synthetic_state_dict(3, "structured")).to(dev)
+    a1 = torch.zeros(int(lib.nerf_amd_packed_bytes(_lib.BF16)), dtype=torch.uint8, device=dev)
+    b1 = torch.zeros(int(lib.nerf_amd_packed_bytes(_lib.BF16_BWD)), dtype=torch.uint8, device=dev)
+    a2, b2 = torch.ones_like(a1), torch.ones_like(b1)
+    _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(flat), _lib.ptr(a1), _lib.BF16, st), "p")
+    _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(flat), _lib.ptr(b1), _lib.BF16_BWD, st), "p")
+    _lib.check(lib.nerf_amd_pack_weights_train(_lib.ptr(flat), _lib.ptr(a2), _lib.ptr(b2), st), "p")
+    torch.cuda.synchronize()
+    assert torch.equal(a1, a2) and torch.equal(b1, b2)
+
+
 def test_train_step_golden_fused(dev, golden, synthetic, oracle):
     """G6 (64 rays x 64 samples, default weights, MSELoss, Adam(lr=5e-4): reference train.py:51-55)
     through the FUSED bf16 kernels: loss, every gradient the fixture holds, gradient norms and the
