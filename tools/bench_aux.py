@@ -49,23 +49,26 @@ with torch.no_grad():
         print(json.dumps({"config": "2: 400x400x64 fp32 (exact-f32 MFMA)", "ms": dt * 1e3, "ray_samples_per_s": s / dt,
                           "tflops": s * FLOP / dt / 1e12, "frac_of_157.3TF": s * FLOP / dt / 157.3e12}))
     if "c3" in which:      # config 3 through the one-call image driver
-        net = net_of("bf16")
+        net = net_of("fp16")
         cam = [800, 800, synthetic.focal_from_fov(800)]
         dt = timed(lambda: render_view(net, pose, cam, N=128, device_rng=True))
         s = 800 * 800 * 128
-        print(json.dumps({"config": "3: 800x800x128 bf16 via render_view (raygen+MLP+composite)", "ms": dt * 1e3,
+        print(json.dumps({"config": "3: 800x800x128 fp16 via render_view (ray generation + the fused render kernel)", "ms": dt * 1e3,
                           "ray_samples_per_s": s / dt, "tflops": s * FLOP / dt / 1e12}))
     if "c4" in which:      # config 4: 800x800, 64 coarse + 128 fine (192 in the fine pass), one GPU
-        nc, nf = net_of("bf16", 0), net_of("bf16", 7)
-        rays = generate_rays(pose, [800, 800, synthetic.focal_from_fov(800)], dev)
-        dt = timed(lambda: render_hierarchical(rays, nc, nf, 64, 128, device_rng=True, seed=3))
-        s = 800 * 800 * (64 + 192)
-        print(json.dumps({"config": "4: 800x800 hierarchical 64 + (64+128) bf16, 1 GPU", "ms": dt * 1e3,
-                          "mlp_evals_per_s": s / dt, "tflops": s * FLOP / dt / 1e12}))
+        from nerf_simple_amd.utils.rendering import render_hierarchical_view
+        for prec in ("fp16", "bf16"):
+            nc, nf = net_of(prec, 0), net_of(prec, 7)
+            cam = [800, 800, synthetic.focal_from_fov(800)]
+            dt = timed(lambda: render_hierarchical_view(nc, nf, pose, cam, 64, 128, device_rng=True, seed=3))
+            s = 800 * 800 * (64 + 192)
+            print(json.dumps({"config": f"4: 800x800 hierarchical 64 + (64+128) {prec}, 1 GPU, ONE library call "
+                                        "(raygen, coarse, sample_pdf, fine)", "ms": dt * 1e3,
+                              "mlp_evals_per_s": s / dt, "tflops": s * FLOP / dt / 1e12}))
 if "pcie" in which:        # reference-compatible jitter: the torch.rand(B,N) stream of the CPU generator (host_rng.py)
     from nerf_simple_amd.utils.rendering import render_nerf
     with torch.no_grad():
-        net = net_of("bf16")
+        net = net_of("fp16")
         rays = generate_rays(pose, [800, 800, synthetic.focal_from_fov(800)], dev)
         for B in (16000, 640000):
             r = rays[:B].contiguous()
@@ -75,7 +78,7 @@ if "pcie" in which:        # reference-compatible jitter: the torch.rand(B,N) st
 if "pcie" in which:        # the same mode through the image driver: batches of 64,000 rays, jitter drawn ahead
     from nerf_simple_amd.utils.rendering import _render_batched
     with torch.no_grad():
-        net = net_of("bf16")
+        net = net_of("fp16")
         rays = generate_rays(pose, [800, 800, synthetic.focal_from_fov(800)], dev)
         for bs in (64000, 640000):
             dt = timed(lambda: _render_batched(rays, net, bs, 128, 2, 6, None, False), warm=1, reps=3)
