@@ -311,6 +311,50 @@ def test_fused_render_equals_two_launch_path(dev, synthetic, precision):
     assert torch.isfinite(out[0]).all() and torch.allclose(out[4].sum(1), out[3], rtol=1e-5, atol=1e-6)
 
 
+def test_fused_render_random_shapes(dev, synthetic):
+    """Property sweep of the fused render against the two-launch path: 40 random (rays, samples) shapes
+    with N from 1 to 768 (ring wrap-around, rays straddling 1..3 tiles, workgroups with one ray or none,
+    explicit sample positions), rgb / disparity / acc / w bit-identical."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    lib = _lib.lib()
+    net = make_net(synthetic, dev, "default", "fp16")
+    code = _lib.FP16
+    packed = net.packed_weights(code)
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 70)).float()
+    allrays = camera_rays([pose], [72, 72, synthetic.focal_from_fov(72)]).float().contiguous().to(dev)
+    st = _lib.stream_ptr(dev)
+    rng = np.random.Generator(np.random.PCG64(2024))
+    shapes = [(1, 1), (300, 1), (77, 2), (9, 767), (2, 768), (513, 255), (64, 257), (1000, 31)]
+    shapes += [(int(rng.integers(1, 1500)), int(rng.choice([5, 33, 63, 96, 127, 129, 191, 200, 256, 300, 511, 513, 640])))
+               for _ in range(32)]
+    for k, (B, N) in enumerate(shapes):
+        B = min(B, max(1, 400000 // N))                       # keep every case under 0.4 M samples
+        rays = allrays[:B].contiguous()
+        tb = torch.linspace(2, 6, N + 1).to(dev)
+        ts_given = k % 3 == 2
+        if ts_given:
+            jit = torch.sort(torch.rand(B, N, generator=torch.Generator().manual_seed(k)) * 4 + 2, dim=1).values.to(dev)
+            flags = _lib.FLAG_TS_GIVEN
+        elif k % 3 == 1:
+            jit, flags = torch.rand(B, N, generator=torch.Generator().manual_seed(k)).to(dev), 0
+        else:
+            jit, flags = None, _lib.FLAG_DEVICE_RNG
+        raw, ts = torch.empty(B, N, 4, device=dev), torch.empty(B, N, device=dev)
+        _lib.check(lib.nerf_amd_mlp_forward_rays(_lib.ptr(rays), _lib.ptr(jit), _lib.ptr(tb), _lib.ptr(packed), code, flags, k,
+                                                 7 * k, _lib.ptr(raw), _lib.ptr(ts), B, N, st), "mlp_forward_rays")
+        two = [torch.empty(s_, device=dev) for s_ in ((B, 3), (B,), (B, N), (B,), (B, N))]
+        _lib.check(lib.nerf_amd_volume_render_rays(_lib.ptr(raw), _lib.ptr(ts), _lib.ptr(rays), *[_lib.ptr(x) for x in two],
+                                                   B, N, st), "volume_render_rays")
+        one = [torch.full(s_, -7.0, device=dev) for s_ in ((B, 3), (B,), (B, N), (B,), (B, N))]
+        _lib.check(lib.nerf_amd_render_forward(_lib.ptr(rays), _lib.ptr(jit), _lib.ptr(tb), _lib.ptr(packed), code, flags, k,
+                                               7 * k, *[_lib.ptr(x) for x in one], None, B, N, st), "render_forward")
+        torch.cuda.synchronize()
+        for n, a, b in zip(NAMES, one, two):
+            same = torch.equal(a, b) or bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all())
+            assert same, (B, N, flags, n)
+
+
 def test_render_rng_consumption(dev, golden, synthetic):
     """Default mode draws ONE torch.rand(B,N) from the CPU generator per call,
     like the reference (utils/rendering.py:28): seeding reproduces the golden."""
