@@ -51,9 +51,9 @@ int64_t  nerf_amd_param_count(void);
 /* bytes of the packed weight image for a precision (the caller allocates it) */
 int64_t  nerf_amd_packed_bytes(int precision);
 /* bytes of workspace nerf_amd_render_forward / _pixels_forward need for B rays x N samples.
- * 0 for the 16-bit precisions up to 768 samples per ray: those run as ONE launch (sampling +
- * encoding + MLP + compositing, samples composited out of LDS) and `workspace` may be NULL;
- * otherwise raw[B,N,4] + ts[B,N] of the two-launch path. */
+ * 0 up to 768 samples per ray: those renders run as ONE launch (sampling + encoding + MLP +
+ * compositing, samples composited out of LDS) and `workspace` may be NULL; longer rays take the
+ * two-launch path through raw[B,N,4] + ts[B,N]. */
 int64_t  nerf_amd_render_workspace_bytes(int precision, int64_t B, int N);
 /* host-side self-check of the packed-weight index math (bijectivity of the
  * k-permutations, offsets, sizes); 0 = consistent.  Used by the CPU tests. */
@@ -200,7 +200,7 @@ int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u,
  * pixels[n_rays,4] = [clip(rgb,0,1), disparity].  Four launches, no host sync, nothing per-sample but
  * ts / w of the coarse pass and ts of the fine pass touches HBM.  u_c[n,Nc] / u_f[n,Nf] explicit
  * uniforms, or NERF_AMD_DEVICE_RNG (both keyed by the global pixel id: sharding-invariant).
- * 16-bit precisions, Nc+Nf <= 512; otherwise NERF_AMD_EUNSUP (compose the three stages instead).
+ * 3 <= Nc <= 256, Nc+Nf <= 512; otherwise NERF_AMD_EUNSUP (compose the three stages instead).
  * Parity unpinned like nerf_amd_sample_pdf (the reference has no hierarchical sampling). */
 int64_t nerf_amd_render_hierarchical_workspace_bytes(int64_t n_rays, int Nc, int Nf);
 int nerf_amd_render_hierarchical_forward(const float* h_pose, int H, int W, float f,

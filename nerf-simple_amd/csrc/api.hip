@@ -48,11 +48,9 @@ inline bool bad_precision(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF1
 inline bool bad_image(int p) { return bad_precision(p) && p != NERF_AMD_BF16_BWD; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
-// the fused render kernel (sampling + MLP + compositing in one launch) serves the 16-bit precisions up
-// to FUSED_RENDER_MAX_N samples per ray
-inline bool fused_render(int precision, int N) {
-    return (precision == NERF_AMD_BF16 || precision == NERF_AMD_FP16) && N <= FUSED_RENDER_MAX_N;
-}
+// the fused render kernels (sampling + MLP + compositing in one launch) serve rays of up to
+// FUSED_RENDER_MAX_N samples, in every precision
+inline bool fused_render(int precision, int N) { return !bad_precision(precision) && N <= FUSED_RENDER_MAX_N; }
 int launch_mlp(const MlpArgs& a, int rays_mode, int precision, hipStream_t s) {
     if (precision == NERF_AMD_F32) return nerf_amd_launch_mlp_f32(&a, rays_mode, s);
     if (precision == NERF_AMD_FP16) return nerf_amd_launch_mlp_f16_16(&a, rays_mode, s);

@@ -9,9 +9,12 @@
 //   * an accumulator register is directly one k-step (4 features, one per lane
 //     group) of the next layer -- no conversion at all between layers;
 //   * the positional encoding uses the accurate ocml sinf/cosf on the exactly
-//     scaled argument, so inputs track the torch-CPU encoder to ~1 ulp.
+//     scaled argument, so inputs track the torch-CPU encoder to ~1 ulp;
+//   * COMP (the render path): compositing in the same launch out of an LDS ring of 1024 samples, as in
+//     mlp_bf16_16.hip (a workgroup owns a contiguous range of rays; composite_device.h is the routine
+//     composite.hip uses, so the pixels are bit-identical to the two-launch path).
 // Peak for this path is the fp32 MFMA rate, 157.3 TFLOP/s (1/16 of bf16).
-#include "nerf_device.h"
+#include "composite_device.h"
 #include <utility>
 
 using namespace nerf_layout;
@@ -27,6 +30,12 @@ constexpr int LDS_W0 = 10 * 1024;
 constexpr int LDS_POSD = LDS_W0 + 2 * LDS_WBUF;               // [wave][2][1 KiB]
 constexpr int LDS_POSX = LDS_POSD + WAVES * 2 * 1024;         // [wave][4][1 KiB]
 constexpr int LDS_TOTAL = LDS_POSX + WAVES * 4 * 1024;
+// COMP only: the sample ring (16 B + 4 B per sample)
+constexpr int RING_PTS = 1024;
+constexpr int LDS_RING_RAW = LDS_TOTAL;
+constexpr int LDS_RING_T = LDS_RING_RAW + RING_PTS * 16;
+constexpr int LDS_TOTAL_COMP = LDS_RING_T + RING_PTS * 4;
+static_assert(LDS_TOTAL_COMP <= 160 * 1024 && RING_PTS - TILE_PTS >= FUSED_RENDER_MAX_N, "ring: an unfinished ray plus a tile");
 static_assert(F32_BIAS_FLOATS * 4 <= LDS_W0, "bias table");
 static_assert(F32_NUM_CHUNKS % 2 == 0, "buffer parity must repeat per tile");
 
@@ -158,16 +167,21 @@ __device__ __forceinline__ float enc_exact(float x, int idx) {
     return (idx & 1) ? co : s;
 }
 
+// p_end: one past the last valid point (a.P, or the end of the workgroup's ray range in the fused render);
+// ring_q0 >= 0: also drop the sample position into the ring slot of this point
 template <bool RAYS>
-__device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base) {
+__device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base, long long p_end,
+                                             int ring_q0) {
     const int col = c.lane & 15, g = c.lane >> 4;
     long long p = tile_base + c.wave * 16 + col;
-    const bool valid = p < a.P;
-    if (!valid) p = a.P - 1;
+    const bool valid = p < p_end;
+    if (!valid) p = p_end - 1;
     PointIn pt;
     if constexpr (RAYS) {
         pt = fetch_point_rays(a, p);
         if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
+        if (ring_q0 >= 0 && valid && g == 0)
+            lds_store<float>(((unsigned)(ring_q0 + c.wave * 16 + col) & (RING_PTS - 1)) * 4, LDS_RING_T, pt.t);
     } else {
         pt = fetch_point_pts(a, p);
     }
@@ -200,8 +214,35 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
     }
 }
 
-template <bool RAYS>
+struct RingSamples {                         // a ray's samples in the workgroup's LDS ring
+    unsigned q0;
+    __device__ __forceinline__ float t(int i) const {
+        return lds_load<float>(((q0 + (unsigned)i) & (RING_PTS - 1)) * 4, LDS_RING_T);
+    }
+    __device__ __forceinline__ f32x4 c(int i) const {
+        return lds_load<f32x4>(((q0 + (unsigned)i) & (RING_PTS - 1)) * 16, LDS_RING_RAW);
+    }
+};
+
+// one tile's 11 layers; leaves rgb / sigma of the wave's 16 points in lane group 0
+__device__ __forceinline__ void run_tile(const Ctx& c, float& sigma, float (&rgb)[3]) {
+    float A[64], B[64];
+    run_layer<0>(c, A, A, sigma, rgb);
+    run_layer<1>(c, A, B, sigma, rgb);
+    run_layer<2>(c, B, A, sigma, rgb);
+    run_layer<3>(c, A, B, sigma, rgb);
+    run_layer<4>(c, B, A, sigma, rgb);
+    run_layer<5>(c, A, B, sigma, rgb);
+    run_layer<6>(c, B, A, sigma, rgb);
+    run_layer<7>(c, A, B, sigma, rgb);
+    run_layer<8>(c, B, A, sigma, rgb);
+    run_layer<9>(c, A, B, sigma, rgb);
+    run_layer<10>(c, B, A, sigma, rgb);
+}
+
+template <bool RAYS, bool COMP>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_f32_kernel(MlpArgs a, long long ntiles) {
+    static_assert(!COMP || RAYS, "the fused render is a rays-mode kernel");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     (void)smem;
     Ctx c;
@@ -228,31 +269,55 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_f32_kernel(Mlp
     }
     __syncthreads();
 
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long long tile_base = tile * TILE_PTS;
-        asm volatile("" : "+s"(c.wave_goff));
-        stage_inputs<RAYS>(c, a, tile_base);
-
-        float A[64], B[64];
-        float sigma, rgb[3];
-        run_layer<0>(c, A, A, sigma, rgb);
-        run_layer<1>(c, A, B, sigma, rgb);
-        run_layer<2>(c, B, A, sigma, rgb);
-        run_layer<3>(c, A, B, sigma, rgb);
-        run_layer<4>(c, B, A, sigma, rgb);
-        run_layer<5>(c, A, B, sigma, rgb);
-        run_layer<6>(c, B, A, sigma, rgb);
-        run_layer<7>(c, A, B, sigma, rgb);
-        run_layer<8>(c, B, A, sigma, rgb);
-        run_layer<9>(c, A, B, sigma, rgb);
-        run_layer<10>(c, B, A, sigma, rgb);
-
-        // rows 0..2 (rgb) / row 256 (sigma) are registers 0..2 / 0 of lane group 0
-        if (c.lane < 16) {
-            const long long p = tile_base + c.wave * 16 + c.lane;
-            if (p < a.P) {
-                const f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
-                *reinterpret_cast<f32x4*>(a.raw + p * 4) = o;
+    if constexpr (!COMP) {
+        for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+            const long long tile_base = tile * TILE_PTS;
+            asm volatile("" : "+s"(c.wave_goff));
+            stage_inputs<RAYS>(c, a, tile_base, a.P, -1);
+            float sigma, rgb[3];
+            run_tile(c, sigma, rgb);
+            // rows 0..2 (rgb) / row 256 (sigma) are registers 0..2 / 0 of lane group 0
+            if (c.lane < 16) {
+                const long long p = tile_base + c.wave * 16 + c.lane;
+                if (p < a.P) {
+                    const f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
+                    *reinterpret_cast<f32x4*>(a.raw + p * 4) = o;
+                }
+            }
+        }
+    } else {
+        // fused render: this workgroup's contiguous range of rays, tile after tile (mlp_bf16_16.hip COMP)
+        const long long B = a.P / a.N;
+        const long long r_lo = (long long)blockIdx.x * B / gridDim.x, r_hi = ((long long)blockIdx.x + 1) * B / gridDim.x;
+        const long long range_base = r_lo * a.N;
+        const int n_pts = (int)((r_hi - r_lo) * a.N);
+        const nerf_composite::RayOut out{a.rgb, a.disp, a.alpha, a.acc, a.w, a.pixels};
+        int next_ray = 0, n_complete = 0;
+        for (int q_tile = 0; q_tile < n_pts; q_tile += TILE_PTS) {
+            asm volatile("" : "+s"(c.wave_goff));
+            stage_inputs<true>(c, a, range_base + q_tile, range_base + n_pts, q_tile & (RING_PTS - 1));
+            float sigma, rgb[3];
+            run_tile(c, sigma, rgb);
+            if (c.lane < 16) {
+                const int local = c.wave * 16 + c.lane;
+                if (q_tile + local < n_pts) {
+                    const f32x4 o = {rgb[0], rgb[1], rgb[2], sigma};
+                    lds_store<f32x4>(((unsigned)(q_tile + local) & (RING_PTS - 1)) * 16, LDS_RING_RAW, o);
+                }
+            }
+            __syncthreads();                                          // every wave's samples of this tile are in the ring
+            const int done_q = q_tile + TILE_PTS < n_pts ? q_tile + TILE_PTS : n_pts;
+            while ((n_complete + 1) * a.N <= done_q) ++n_complete;
+            if (n_complete - next_ray >= WAVES || done_q + TILE_PTS - next_ray * a.N > RING_PTS || done_q == n_pts) {
+                for (int ray = next_ray + c.wave; ray < n_complete; ray += WAVES) {
+                    const long long gray = r_lo + ray;
+                    const float* d = a.rays + gray * 6 + 3;
+                    const float dnorm = nerf_composite::unit_dir_norm(d[0], d[1], d[2], true);
+                    const RingSamples src{(unsigned)(ray * a.N) & (RING_PTS - 1)};
+                    nerf_composite::composite_ray(src, a.N, c.lane, dnorm, gray, out);
+                }
+                next_ray = n_complete;
+                __syncthreads();                                      // the next tile's prologue rewrites ring slots read above
             }
         }
     }
@@ -271,10 +336,13 @@ extern "C" int nerf_amd_launch_mlp_f32(const MlpArgs* args, int rays_mode, hipSt
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (e != hipSuccess) return (int)e;
     const long long grid = ntiles < cus ? ntiles : cus;
-    auto kern = rays_mode ? nerf_mlp_f32_kernel<true> : nerf_mlp_f32_kernel<false>;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    const bool comp = a.rgb || a.disp || a.acc || a.alpha || a.w || a.pixels;
+    if (comp && (!rays_mode || a.N > FUSED_RENDER_MAX_N || a.P / grid + a.N >= (1ll << 31))) return -2;
+    auto kern = comp ? nerf_mlp_f32_kernel<true, true>
+                     : (rays_mode ? nerf_mlp_f32_kernel<true, false> : nerf_mlp_f32_kernel<false, false>);
+    const int lds = comp ? LDS_TOTAL_COMP : LDS_TOTAL;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), LDS_TOTAL, stream, a, ntiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), lds, stream, a, ntiles);
     return (int)hipGetLastError();
 }

@@ -395,7 +395,7 @@ def render_hierarchical_view(net_coarse, net_fine, pose, cam_params, Nc=64, Nf=1
     no torch arithmetic on the path).  Returns pixels [n,4] = [r,g,b,disparity] on the GPU.
     u_c [n,Nc] / u_f [n,Nf]: explicit uniforms for these pixels; default: the reference-style CPU
     draws torch.rand(n,Nc) then torch.rand(n,Nf); device_rng=True: counter RNG keyed by global pixel id.
-    16-bit precisions only (the fused render kernels); parity unpinned (no reference counterpart)."""
+    Parity unpinned (no reference counterpart)."""
     import numpy as np
     dev = next(net_coarse.parameters()).device
     H, W, f = int(cam_params[0]), int(cam_params[1]), float(cam_params[2])

@@ -43,8 +43,8 @@ def test_introspection(lib):
     assert lib.nerf_amd_packed_bytes(1) == lib.nerf_amd_packed_bytes(2) == 1172 * 1024 + 2464 * 4
     assert lib.nerf_amd_packed_bytes(0) == 2360 * 1024 + 154 * 16 * 4
     assert lib.nerf_amd_packed_bytes(7) < 0
-    assert lib.nerf_amd_render_workspace_bytes(0, 16000, 128) >= 16000 * 128 * 20       # fp32: raw + ts
-    assert lib.nerf_amd_render_workspace_bytes(1, 16000, 128) == 0                      # 16-bit: one fused launch
+    for prec in (0, 1, 2):                                                              # one fused launch: no workspace
+        assert lib.nerf_amd_render_workspace_bytes(prec, 16000, 128) == 0
     assert lib.nerf_amd_render_workspace_bytes(2, 16000, 768) == 0
     assert lib.nerf_amd_render_workspace_bytes(1, 100, 769) >= 100 * 769 * 20           # ray longer than the LDS ring
     assert lib.nerf_amd_render_workspace_bytes(1, -1, 128) < 0
@@ -138,7 +138,7 @@ def test_abi_argument_errors(lib):
     assert lib.nerf_amd_volume_render_backward(one, one, one, 3, one, null, null, null, null, one, 4, 1024, null) == EUNSUP
     assert lib.nerf_amd_render_forward(one, null, one, one, 1, 0, 0, 0, one, one, null, one, null, one, 4, 8, null) == EINVAL  # no jitter
     assert lib.nerf_amd_render_forward(one, one, null, one, 1, 0, 0, 0, one, one, null, one, null, one, 4, 8, null) == EINVAL  # no tbins
-    assert lib.nerf_amd_render_forward(one, one, one, one, 0, 0, 0, 0, one, one, null, one, null, null, 4, 8, null) == EINVAL  # no workspace on the two-launch (fp32) path
+    assert lib.nerf_amd_render_forward(one, one, one, one, 0, 0, 0, 0, one, one, null, one, null, null, 4, 800, null) == EINVAL  # no workspace on the two-launch path (N > 768)
     assert lib.nerf_amd_sample_pdf(one, one, one, 0, 0, 0, one, 4, 2, 8, null) == EUNSUP      # Nc < 3
     assert lib.nerf_amd_sample_pdf(one, one, one, 0, 0, 0, one, 4, 300, 8, null) == EUNSUP    # Nc > 256
     assert lib.nerf_amd_generate_rays(one, 10, 10, ctypes.c_float(5.0), 90, 20, one, null) == EINVAL   # past the image
