@@ -89,10 +89,18 @@ def test_no_cpu_fallback():
         xyz.positional_encoder(torch.zeros(4, 6))
     with pytest.raises(RuntimeError):
         rendering.volume_render(torch.zeros(2, 4, 4), torch.zeros(2, 4), torch.zeros(2, 3))
+    state = torch.get_rng_state()
     with pytest.raises(RuntimeError):
         rendering.render_nerf(torch.zeros(2, 6), nets.Nerf(), 8)
+    assert torch.equal(torch.get_rng_state(), state), "a refused call must not consume the CPU generator"
     with pytest.raises(AssertionError):
         xyz.gamma([1.0, 2.0])
+    # training precision contract, checked without a GPU: fp32 has no training kernels
+    from nerf_simple_amd import training
+    with pytest.raises(RuntimeError, match="fp32 training is not supported"):
+        training._check_trainable("fp32")
+    training._check_trainable("fp16")
+    training._check_trainable("bf16")
 
 
 def test_state_dict_contract(synthetic):

@@ -75,6 +75,16 @@ def _worker(rank, world, port, job, tmp):
             want = torch.arange(flat.numel(), dtype=torch.float32) * (sum(range(1, world + 1)) / world)
             assert torch.equal(flat, want)                       # reduced in place, no copies
             assert all(p_.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p_ in params)
+            # the flat-vector form GraphedTrainStep calls between its two graphs
+            x = torch.full((7,), float(rank + 1))
+            assert parallel.allreduce_flat_(x) is x and bool((x == sum(range(1, world + 1)) / world).all())
+            # ragged pixel shards gathered into a caller-provided table
+            n_tot = 5
+            lo, hi = parallel.shard_range(n_tot, rank, world)
+            shard = torch.arange(lo, hi, dtype=torch.float32).reshape(-1, 1).repeat(1, 4)
+            table = torch.full((n_tot, 4), -1.0)
+            assert parallel.gather_pixels(shard, n_tot, out=table) is table
+            assert torch.equal(table[:, 0], torch.arange(n_tot, dtype=torch.float32))
             # and a list that is NOT one buffer takes the bucket path
             loose = [torch.zeros(3, requires_grad=True), torch.zeros(2, requires_grad=True)]
             for p_ in loose:
