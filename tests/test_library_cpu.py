@@ -89,9 +89,10 @@ def test_no_cpu_fallback():
         xyz.positional_encoder(torch.zeros(4, 6))
     with pytest.raises(RuntimeError):
         rendering.volume_render(torch.zeros(2, 4, 4), torch.zeros(2, 4), torch.zeros(2, 3))
+    net = nets.Nerf()                       # (its nn.Linear initialisers draw from the CPU generator)
     state = torch.get_rng_state()
     with pytest.raises(RuntimeError):
-        rendering.render_nerf(torch.zeros(2, 6), nets.Nerf(), 8)
+        rendering.render_nerf(torch.zeros(2, 6), net, 8)
     assert torch.equal(torch.get_rng_state(), state), "a refused call must not consume the CPU generator"
     with pytest.raises(AssertionError):
         xyz.gamma([1.0, 2.0])
