@@ -129,6 +129,15 @@ struct State {
     // fused render only (COMP)
     long long p_end;                  // one past this workgroup's last point (uniform)
     unsigned ring_q0;                 // ring slot of the tile's point 0 (uniform)
+    struct WFrag* wf;                 // the coming chunk's first weight fragments (outlive a tile)
+};
+// The first AHEAD weight fragments and the first bias vector of the chunk that runs next, requested
+// right behind the barrier that publishes its buffer -- which the inference kernels place three
+// fragments BEFORE the end of the previous chunk, so the LDS round trip of these reads is covered by
+// that chunk's last six MFMAs instead of idling the matrix pipe at every chunk start.
+struct WFrag {
+    ex8 a[4];
+    f32x4 bias0;
 };
 
 template <bool RELU>
@@ -245,13 +254,37 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
                   "pending pair finished too late");
     const unsigned wb = c.b_wread[CC & 1];
     const unsigned xb = D.extra_kind == 1 ? c.b_posx : c.b_posd;
+    // the chunk that runs next (cyclic: the last chunk of a tile prefetches the first one of the next tile)
+    constexpr int NCC = (CC + 1) % NUM_CHUNKS;
+    constexpr int NL = chunk_layer(NCC);
+    constexpr int NF = chunk_tiles(NCC) * (layer_desc(NL).chain_k / 32 + layer_desc(NL).extra_slots / 32);
+    constexpr int NBIAS_OFF = LDS_BIAS + (b16_bias_off(NL) + 16 * (NCC - chunk_first(NL)) * TPC) * 4;
+    const unsigned nwb = c.b_wread[NCC & 1];
+    // Where the chunk's barrier sits, as a fragment index: the training forward keeps it at the end (its
+    // counted vmcnt covers every store of the chunk); the inference kernels take it TAIL fragments early.
+    constexpr int TAIL = 3;
+    constexpr int FB = (SAVE || F <= TAIL) ? F : F - TAIL;
+    constexpr int VMEM_N = pair_vmem_ops<SAVE>(PL, PQ) + (NT == 4 ? pair_vmem_ops<SAVE>(L, 2 * C) : 0);
+    WFrag& wf = *st.wf;
+    auto barrier_and_prefetch = [&]() {
+        // Every fragment read of this chunk has been issued at least two fragment slots ago (AHEAD = 4,
+        // TAIL = 3): lgkmcnt(0) is free, and it makes the buffer reusable -- no wave reads it after its
+        // barrier.  vmcnt: this wave's LDS-DMA pieces of the next chunk (issued first in this chunk) have
+        // landed; the training forward's stores behind them may fly on.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        chunk_barrier<VMEM_N>();
+#pragma unroll
+        for (int f = 0; f < AHEAD && f < NF; ++f) wf.a[f] = lds_load<ex8>(nwb, f * 1024);
+        wf.bias0 = lds_load<f32x4>(c.b_bias, NBIAS_OFF);
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     Stage<CC>::issue(c);
     __builtin_amdgcn_sched_barrier(0);   // every other vector-memory instruction of the chunk stays behind the DMA
 
     ex8 a[AHEAD];
 #pragma unroll
-    for (int f = 0; f < AHEAD && f < F; ++f) a[f] = lds_load<ex8>(wb, f * 1024);
+    for (int f = 0; f < AHEAD && f < F; ++f) a[f] = wf.a[f];       // requested behind the previous barrier
     ex8 bx[NCB][KS_EXTRA > 0 ? KS_EXTRA : 1];
     if constexpr (KS_EXTRA > 0) {
 #pragma unroll
@@ -261,7 +294,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
     }
     f32x4 acc[NCB][NT];
     // register i of lane group g is row 16*rt + 4g + i: one 16-B bias read per tile
-    acc[0][0] = lds_load<f32x4>(c.b_bias, BIAS_OFF);
+    acc[0][0] = wf.bias0;
     for (int cb = 1; cb < NCB; ++cb) acc[cb][0] = acc[0][0];
     __builtin_amdgcn_sched_barrier(0);
 
@@ -270,6 +303,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int f = t * KS + ks;
+            if (f == FB) barrier_and_prefetch();
             const ex8 as = a[f % AHEAD];
             if (f + AHEAD < F) a[f % AHEAD] = lds_load<ex8>(wb, (f + AHEAD) * 1024);
             if (t + 1 < NT && ks == KS / 2) {
@@ -309,8 +343,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
         st.pend[cb][0] = acc[cb][NT >= 2 ? NT - 2 : 0];
         st.pend[cb][1] = acc[cb][NT - 1];
     }
-    // this wave's LDS-DMA pieces (issued first in this chunk) have landed; the stores behind them may fly on
-    chunk_barrier<pair_vmem_ops<SAVE>(PL, PQ) + (NT == 4 ? pair_vmem_ops<SAVE>(L, 2 * C) : 0)>();
+    if constexpr (FB == F) barrier_and_prefetch();
 }
 
 __host__ __device__ constexpr int prev_layer(int L, int C) { return C > 0 ? L : L - 1; }
@@ -483,12 +516,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's LDS-DMA pieces have landed
     __syncthreads();
+    WFrag wf;                                           // chunk 0's first fragments (chunk_step hands them on)
+    {
+        constexpr int F0 = chunk_tiles(0) * (layer_desc(0).chain_k / 32 + layer_desc(0).extra_slots / 32);
+#pragma unroll
+        for (int f = 0; f < 4 && f < F0; ++f) wf.a[f] = lds_load<ex8>(c.b_wread[0], f * 1024);
+        wf.bias0 = lds_load<f32x4>(c.b_bias, LDS_BIAS + b16_bias_off(0) * 4);
+    }
 
     if constexpr (!COMP) {
         for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
             const long long tile_base = tile * TILE_PTS;
             asm volatile("" : "+s"(c.wave_goff));
             State st;
+            st.wf = &wf;
             st.acts = reinterpret_cast<char*>(a.acts);
             st.P = a.P;
             st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
@@ -517,6 +558,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
             const long long tile_base = range_base + q_tile;
             asm volatile("" : "+s"(c.wave_goff));
             State st;
+            st.wf = &wf;
             st.acts = nullptr;
             st.P = a.P;
             st.mask_tile = 0;
