@@ -279,7 +279,14 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    Stage<CC>::issue(c);
+    // DMA of the next chunk: the training forward issues all pieces first (its counted vmcnt assumes every
+    // store of the chunk behind them); the inference kernels, whose first fragments are already in
+    // registers, start their MFMAs at once and issue one piece every SPREAD MFMAs -- provided the last
+    // piece still goes out well before the MFMA in front of which the barrier publishes that buffer
+    // (a piece issued behind the barrier would be read by the prefetch before it has landed)
+    constexpr int SPREAD = 4;
+    constexpr bool DMA_SPREAD = !SAVE && 1 + SPREAD * (Stage<CC>::PIECES - 1) + 8 <= FB * NCB;
+    if constexpr (!DMA_SPREAD) Stage<CC>::issue(c);
     __builtin_amdgcn_sched_barrier(0);   // every other vector-memory instruction of the chunk stays behind the DMA
 
     ex8 a[AHEAD];
@@ -318,6 +325,9 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
                 if (ks < KS_CHAIN) bs = in[cb][ks < KS_CHAIN ? ks : 0];
                 else bs = bx[cb][KS_EXTRA > 0 ? (ks - KS_CHAIN < KS_EXTRA ? ks - KS_CHAIN : 0) : 0];
                 acc[cb][t] = NERF_MFMA(as, bs, acc[cb][t], 0, 0, 0);
+                if constexpr (DMA_SPREAD) {
+                    if (m % SPREAD == 1 && m / SPREAD < Stage<CC>::PIECES) Stage<CC>::issue_piece(c, m / SPREAD);
+                }
                 // ---- epilogue pieces in this MFMA's shadow
                 if constexpr (PL >= 0) {
                     if (m >= PEND_M0 && m < PEND_M0 + 4 * NCB / PEND_PER) {
