@@ -47,15 +47,18 @@ namespace {
 constexpr int NCB = 2;
 constexpr int WAVES = 16 / NCB;
 constexpr int TILE_PTS = WAVES * 16 * NCB;
-constexpr int TPC = 4;                        // 16-row output tiles per weight chunk (64 rows)
+// 16-row output tiles per weight chunk: 4 (64 rows, 8..40 KiB), and 8 for the K = 64 first layer, whose
+// tiles are two fragments each (one barrier per 16 MFMAs otherwise).  The chunk count stays even: the
+// double buffer's parity is cyclic over tiles.
+__host__ __device__ constexpr int tpc(int L) { return L == 0 ? 8 : 4; }
 
-__host__ __device__ constexpr int layer_chunks(int L) { return (b16_mt(L) + TPC - 1) / TPC; }
+__host__ __device__ constexpr int layer_chunks(int L) { return (b16_mt(L) + tpc(L) - 1) / tpc(L); }
 __host__ __device__ constexpr int chunk_first(int L) {
     int c = 0;
     for (int i = 0; i < L; ++i) c += layer_chunks(i);
     return c;
 }
-constexpr int NUM_CHUNKS = chunk_first(NUM_LAYERS);           // 40
+constexpr int NUM_CHUNKS = chunk_first(NUM_LAYERS);           // 38
 __host__ __device__ constexpr int chunk_layer(int cc) {
     int L = 0;
     while (cc >= layer_chunks(L)) { cc -= layer_chunks(L); ++L; }
@@ -63,13 +66,13 @@ __host__ __device__ constexpr int chunk_layer(int cc) {
 }
 __host__ __device__ constexpr int chunk_tiles(int cc) {
     const int L = chunk_layer(cc), C = cc - chunk_first(L);
-    const int left = b16_mt(L) - C * TPC;
-    return left < TPC ? left : TPC;
+    const int left = b16_mt(L) - C * tpc(L);
+    return left < tpc(L) ? left : tpc(L);
 }
 __host__ __device__ constexpr int chunk_kib(int cc) { return chunk_tiles(cc) * b16_ks(chunk_layer(cc)); }
 __host__ __device__ constexpr int chunk_off_kib(int cc) {
     const int L = chunk_layer(cc), C = cc - chunk_first(L);
-    return b16_layer_off_kib(L) + C * TPC * b16_ks(L);
+    return b16_layer_off_kib(L) + C * tpc(L) * b16_ks(L);
 }
 
 constexpr int LDS_WBUF = 40 * 1024;
@@ -229,7 +232,23 @@ __host__ __device__ constexpr int pair_vmem_ops(int L, int Q) {
     return NCB + ((layer_desc(L).relu != 0 && (Q & 3) == 3) ? NCB : 0);    // activations (+ a mask dword) per block
 }
 
-// ---- one chunk: NT 16-row tiles of layer L starting at tile 4C -------------------
+// the same summed over the pairs a chunk finishes itself (pairs P0 .. P0 + N - 1 of layer L)
+template <bool SAVE>
+__host__ __device__ constexpr int chunk_pair_vmem_ops(int L, int P0, int N) {
+    int n = 0;
+    for (int j = 0; j < N; ++j) n += pair_vmem_ops<SAVE>(L, P0 + j);
+    return n;
+}
+// epilogue piece `i` of in-chunk pair j (a compile-time pair index is needed: dispatch over the few values)
+template <int L, int P0, int N, bool SAVE, int J = 0>
+__device__ __forceinline__ void in_chunk_epilogue(int j, int i, const f32x4 (&acc)[NCB][2], ex8 (&dst)[NCB][8], State& st) {
+    if constexpr (J < N) {
+        if (j == J) epilogue_piece<L, P0 + J, SAVE>(i, acc, dst, st);
+        else in_chunk_epilogue<L, P0, N, SAVE, J + 1>(j, i, acc, dst, st);
+    }
+}
+
+// ---- one chunk: NT 16-row tiles of layer L starting at tile C * tpc(L) -------------------
 // PL/PQ: layer / pair of the pending accumulators handed over by the previous chunk.
 template <int L, int C, int PL, int PQ, bool SAVE>
 __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NCB][8], ex8 (&out)[NCB][8]) {
@@ -239,7 +258,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
     constexpr int KS = KS_CHAIN + KS_EXTRA;
     constexpr int CC = chunk_first(L) + C;
     constexpr int NT = chunk_tiles(CC);
-    constexpr int RT0 = C * TPC;
+    constexpr int RT0 = C * tpc(L);
     constexpr int F = NT * KS;                      // weight fragments (each feeds 2 MFMAs)
     constexpr int AHEAD = 4;                         // weight fragments in flight ahead of their MFMAs (2..8 measure alike)
     constexpr int BIAS_OFF = LDS_BIAS + (b16_bias_off(L) + 16 * RT0) * 4;
@@ -248,7 +267,12 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
     constexpr int MT = NCB * KS;                      // MFMAs per row tile
     constexpr int PEND_M0 = (L == 10) ? 0 : (NT * MT >= 4 * NCB + 4 ? 2 : 0);
     constexpr int PEND_PER = (L == 10) ? 2 : 1;     // pieces per MFMA for the pending pair
+    // Row-tile pairs of this chunk: pair j (tiles 2j, 2j+1; layer pair PAIR0 + j) gets its epilogue in the shadow
+    // of the MFMAs of pair j + 1, starting at MFMA PAIR_M0 + j * 2 MT; the last pair is handed to the next chunk
+    constexpr int PAIR0 = RT0 / 2;
+    constexpr int NPAIR_IN = NT >= 4 ? NT / 2 - 1 : 0;
     constexpr int PAIR_M0 = 2 * MT + (MT >= 4 * NCB + 2 ? 2 : 0);
+    static_assert(NT < 4 || NT % 2 == 0, "whole pairs per chunk");
     // a pending pair of the PREVIOUS layer is this layer's k-step PQ, first read by MFMA 2*PQ
     static_assert(PL < 0 || PL == L || (PL == 8 && PQ == 8) || NCB * PQ >= PEND_M0 + 4 * NCB / PEND_PER,
                   "pending pair finished too late");
@@ -258,13 +282,13 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
     constexpr int NCC = (CC + 1) % NUM_CHUNKS;
     constexpr int NL = chunk_layer(NCC);
     constexpr int NF = chunk_tiles(NCC) * (layer_desc(NL).chain_k / 32 + layer_desc(NL).extra_slots / 32);
-    constexpr int NBIAS_OFF = LDS_BIAS + (b16_bias_off(NL) + 16 * (NCC - chunk_first(NL)) * TPC) * 4;
+    constexpr int NBIAS_OFF = LDS_BIAS + (b16_bias_off(NL) + 16 * (NCC - chunk_first(NL)) * tpc(NL)) * 4;
     const unsigned nwb = c.b_wread[NCC & 1];
     // Where the chunk's barrier sits, as a fragment index: the training forward keeps it at the end (its
     // counted vmcnt covers every store of the chunk); the inference kernels take it TAIL fragments early.
     constexpr int TAIL = 3;
     constexpr int FB = (SAVE || F <= TAIL) ? F : F - TAIL;
-    constexpr int VMEM_N = pair_vmem_ops<SAVE>(PL, PQ) + (NT == 4 ? pair_vmem_ops<SAVE>(L, 2 * C) : 0);
+    constexpr int VMEM_N = pair_vmem_ops<SAVE>(PL, PQ) + chunk_pair_vmem_ops<SAVE>(L, PAIR0, NPAIR_IN);
     WFrag& wf = *st.wf;
     auto barrier_and_prefetch = [&]() {
         // Every fragment read of this chunk has been issued at least two fragment slots ago (AHEAD = 4,
@@ -339,10 +363,13 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
                         }
                     }
                 }
-                if (NT == 4 && m >= PAIR_M0 && m < PAIR_M0 + 4 * NCB) {
-                    f32x4 pr[NCB][2];
-                    for (int q_ = 0; q_ < NCB; ++q_) { pr[q_][0] = acc[q_][0]; pr[q_][1] = acc[q_][NT > 1 ? 1 : 0]; }
-                    epilogue_piece<L, 2 * C, SAVE>(m - PAIR_M0, pr, out, st);
+                if constexpr (NPAIR_IN > 0) {
+                    const int j = (m - PAIR_M0) / (2 * MT), pm = (m - PAIR_M0) - j * (2 * MT);
+                    if (m >= PAIR_M0 && j < NPAIR_IN && pm < 4 * NCB) {
+                        f32x4 pr[NCB][2];
+                        for (int q_ = 0; q_ < NCB; ++q_) { pr[q_][0] = acc[q_][2 * j]; pr[q_][1] = acc[q_][2 * j + 1]; }
+                        in_chunk_epilogue<L, PAIR0, NPAIR_IN, SAVE>(j, pm, pr, out, st);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -358,9 +385,9 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
 
 __host__ __device__ constexpr int prev_layer(int L, int C) { return C > 0 ? L : L - 1; }
 __host__ __device__ constexpr int prev_pair(int L, int C) {
-    // pending pair when chunk (L, C) starts: same layer -> pair 2C-1; else the previous
+    // pending pair when chunk (L, C) starts: same layer -> the last pair of chunk C-1; else the previous
     // layer's last pair (L8 ends with its lone sigma tile, marked as pair 8)
-    return C > 0 ? 2 * C - 1 : (L > 0 ? (L - 1 == 8 ? 8 : b16_mt(L - 1) / 2 - 1) : 0);
+    return C > 0 ? C * tpc(L) / 2 - 1 : (L > 0 ? (L - 1 == 8 ? 8 : b16_mt(L - 1) / 2 - 1) : 0);
 }
 
 template <int L, bool SAVE, int... Cs>
