@@ -47,7 +47,7 @@ H = W = 800
 N_SAMPLES = 128
 TRAIN_RAYS, TRAIN_SAMPLES = 4096, 64   # per GPU (reference configs/lego.yaml:12; BASELINE config 5)
 DW_BYTES_PER_POINT = 11_776            # operands nerf_amd_param_gradients reads once per point
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_bench_pmc.json")
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r02_bench_pmc.json", "r02b_train_pmc.json")]
 
 
 def parse():
@@ -141,16 +141,17 @@ def cpu_baseline(sd, rays_cpu, n_rays):
 
 
 def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed PMC summary (separate rocprofv3 --pmc passes of
+    """HBM bytes per launch of a kernel from the committed PMC summaries (separate rocprofv3 --pmc passes of
     this same command, tools/profile_gpu.sh): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 wide-read correction,
-    MI355X_MICROARCH.md section HBM), both in KB.  None if the summary does not hold that kernel."""
-    try:
-        summary = json.load(open(PMC_SUMMARY))
-    except (OSError, ValueError):
-        return None, None
-    for name, c in summary.get("kernels", {}).items():
-        if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
-            return (c["WRITE_SIZE"] + 2.0 * c["FETCH_SIZE"]) * 1024.0, os.path.relpath(PMC_SUMMARY, ROOT)
+    MI355X_MICROARCH.md section HBM), both in KB.  None if no summary holds that kernel."""
+    for path in PMC_SUMMARIES:
+        try:
+            summary = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        for name, c in summary.get("kernels", {}).items():
+            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                return (c["WRITE_SIZE"] + 2.0 * c["FETCH_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -374,8 +375,7 @@ def run_train(args):
                        "rays_per_gpu": B, "samples_per_ray": N, "global_batch_rays": B * world,
                        "parallelism": f"data-parallel x{world}" + (" + all_reduce of the flat 2.38 MB gradient" if world > 1 else "")},
             "ranks": seen, "final_loss": loss,
-            "roofline": {"bound": "hbm", "kernel": "dw_gemm_kernel (nerf_amd_param_gradients, includes its memset and "
-                                                    "the drgb pack kernel)",
+            "roofline": {"bound": "hbm", "kernel": "dw_gemm_kernel (timed: nerf_amd_param_gradients = zero fill + d_raw pack + dw_gemm)",
                          "achieved": achieved, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / PEAK_HBM,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": dw_ms,
                          "algorithmic_bytes_per_point": DW_BYTES_PER_POINT,
