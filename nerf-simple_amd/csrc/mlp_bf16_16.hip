@@ -239,6 +239,17 @@ __host__ __device__ constexpr int chunk_pair_vmem_ops(int L, int P0, int N) {
     for (int j = 0; j < N; ++j) n += pair_vmem_ops<SAVE>(L, P0 + j);
     return n;
 }
+template <bool SAVE>
+__host__ __device__ constexpr int vmem_before_barrier(int L, int PL, int PQ, int pair0, int npair_in, int pend_m0, int pend_per,
+                                                      int pair_m0, int mt, int m_limit) {
+    int n = 0;
+    for (int cb = 0; cb < NCB; ++cb) {
+        if (PL >= 0 && pend_m0 + (4 * cb + 3) / pend_per < m_limit) n += pair_vmem_ops<SAVE>(PL, PQ) / NCB;
+        for (int j = 0; j < npair_in; ++j)
+            if (pair_m0 + j * 2 * mt + 4 * cb + 3 < m_limit) n += pair_vmem_ops<SAVE>(L, pair0 + j) / NCB;
+    }
+    return n;
+}
 // epilogue piece `i` of in-chunk pair j (a compile-time pair index is needed: dispatch over the few values)
 template <int L, int P0, int N, bool SAVE, int J = 0>
 __device__ __forceinline__ void in_chunk_epilogue(int j, int i, const f32x4 (&acc)[NCB][2], ex8 (&dst)[NCB][8], State& st) {
@@ -284,11 +295,14 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
     constexpr int NF = chunk_tiles(NCC) * (layer_desc(NL).chain_k / 32 + layer_desc(NL).extra_slots / 32);
     constexpr int NBIAS_OFF = LDS_BIAS + (b16_bias_off(NL) + 16 * (NCC - chunk_first(NL)) * tpc(NL)) * 4;
     const unsigned nwb = c.b_wread[NCC & 1];
-    // Where the chunk's barrier sits, as a fragment index: the training forward keeps it at the end (its
-    // counted vmcnt covers every store of the chunk); the inference kernels take it TAIL fragments early.
+    // Where the chunk's barrier sits, as a fragment index: TAIL fragments before the end of the chunk.
     constexpr int TAIL = 3;
-    constexpr int FB = (SAVE || F <= TAIL) ? F : F - TAIL;
-    constexpr int VMEM_N = pair_vmem_ops<SAVE>(PL, PQ) + chunk_pair_vmem_ops<SAVE>(L, PAIR0, NPAIR_IN);
+    constexpr int FB = F <= TAIL ? F : F - TAIL;
+    // The training forward's counted wait: vector-memory instructions this wave issues between its DMA pieces
+    // (first in the chunk) and the barrier, i.e. the activation / mask stores of the epilogue pieces that sit in
+    // front of MFMA FB * NCB (piece 4 cb + 3 of a pair carries column block cb's stores); the ones behind the
+    // barrier are older than the next chunk's DMA and need no count.
+    constexpr int VMEM_N = vmem_before_barrier<SAVE>(L, PL, PQ, PAIR0, NPAIR_IN, PEND_M0, PEND_PER, PAIR_M0, MT, FB * NCB);
     WFrag& wf = *st.wf;
     auto barrier_and_prefetch = [&]() {
         // Every fragment read of this chunk has been issued at least two fragment slots ago (AHEAD = 4,
