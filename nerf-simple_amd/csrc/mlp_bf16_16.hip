@@ -202,7 +202,7 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
                 // The 16 lanes of a quarter-wave then write 256 contiguous bytes.
                 char* tb = st.acts + (act_offset_bytes(L, st.P) + st.tile * ACT_BLOCK_BYTES);
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)ACT_BLOCK_BYTES, 0x00020000);
-                store_granule(rs, st.loff[cb], Q * 16384, w);
+                store_granule<2>(rs, st.loff[cb], Q * 16384, w);
             }
             if constexpr (D.relu != 0) {
                 // ReLU mask for the backward pass: one bit per feature (post-ReLU bf16 != 0), collected
