@@ -162,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
         for (int k = 0; k < DMA_PER_SLAB; ++k) {
             lds_void* dst = reinterpret_cast<lds_void*>(reinterpret_cast<lds_char*>(0) + slot * SLOTB + ldst[k]);
             const unsigned off = (voff[k] == OUTSIDE || vrow[k] >= rows_left) ? OUTSIDE : voff[k] + vadd;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, off, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 16, off, 0, 0, 2);      // aux 2 = non-temporal: every operand byte is read once
         }
     };
 

@@ -143,7 +143,7 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
         // pieces with lane group g ^ 1; unconditional buffer store (forward epilogue_piece)
         char* tb = st.dys + (act_offset_bytes(LOUT, st.P) + st.tile * ACT_BLOCK_BYTES);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)ACT_BLOCK_BYTES, 0x00020000);
-        store_granule(rs, st.loff[cb], Q * 16384, w);
+        store_granule<2>(rs, st.loff[cb], Q * 16384, w);      // non-temporal: see store_granule
     }
 }
 

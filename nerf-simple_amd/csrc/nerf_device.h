@@ -70,9 +70,12 @@ __host__ __device__ constexpr int block_lane_offset(int g, int local) { return s
 // register (its hazard table says a register soffset delays the next instruction enough), so the
 // padding is explicit here: the trailing asm keeps the four data registers live past the store
 // and supplies the wait states.
-// AUX: cache policy bits of the store (0 = default, 2 = non-temporal).  The training forward streams 1.3 GB of
-// activations nothing reads again before they have left every cache: non-temporal stores took 5 % off that
-// kernel (361 -> 342 us at 4096 x 64, one process A/B); the dX chain measured 2 % slower with them and keeps 0.
+// AUX: cache policy bits of the store (0 = default, 2 = non-temporal).  A training step streams 1.3 GB of
+// activations and 1.2 GB of dY that nothing reads before they have left every cache, and the dW kernel reads
+// each of those bytes once.  Measured on the whole step (4096 x 64, bench.py --mode train, one box): default
+// policy everywhere 1.37-1.40 ms; forward stores non-temporal 1.31; + dX-chain stores 1.23; + dW's LDS-DMA loads
+// 1.18 ms.  (Timed alone, the dX kernel is 2 % SLOWER with non-temporal stores: the gain is what the
+// neighbouring kernels no longer lose to its write-allocated lines.)
 template <int AUX = 0>
 __device__ __forceinline__ void store_granule(__amdgpu_buffer_rsrc_t rs, int voffset, int soffset, u32x4 w) {
     const auto s0 = __builtin_amdgcn_permlane16_swap(w[0], w[2], false, false);
