@@ -47,7 +47,7 @@ H = W = 800
 N_SAMPLES = 128
 TRAIN_RAYS, TRAIN_SAMPLES = 4096, 64   # per GPU (reference configs/lego.yaml:12; BASELINE config 5)
 DW_BYTES_PER_POINT = 11_776            # operands nerf_amd_param_gradients reads once per point
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r02_bench_pmc.json", "r02b_train_pmc.json")]
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r02_bench_pmc.json", "r02e_train_pmc.json")]
 
 
 def parse():
