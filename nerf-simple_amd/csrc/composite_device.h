@@ -68,8 +68,9 @@ __device__ __forceinline__ void composite_ray(const Src& src, int N, int lane, f
         const float wt = __fmul_rn(a, T);
         carry = __fmul_rn(carry, __shfl(incl, 63));
         if (valid) {
-            if (o.alpha) o.alpha[ray * N + i] = a;
-            if (o.w) o.w[ray * N + i] = wt;
+            // per-sample outputs are streamed (8 B per sample when requested): non-temporal stores
+            if (o.alpha) __builtin_nontemporal_store(a, o.alpha + ray * N + i);
+            if (o.w) __builtin_nontemporal_store(wt, o.w + ray * N + i);
             sr = __fmaf_rn(wt, c[0], sr);
             sg = __fmaf_rn(wt, c[1], sg);
             sb = __fmaf_rn(wt, c[2], sb);

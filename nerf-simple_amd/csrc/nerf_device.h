@@ -153,14 +153,15 @@ __device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long 
     const float ox = ray[0], oy = ray[1], oz = ray[2];
     const float dx = ray[3], dy = ray[4], dz = ray[5];
     float t;
+    // jitter / sample positions are read once: non-temporal loads keep 4 B per sample out of the caches
     if (a.flags & NERF_FLAG_TS_GIVEN) {
-        t = a.u[p];
+        t = __builtin_nontemporal_load(a.u + p);
     } else {
         float u;
         if (a.flags & NERF_FLAG_DEVICE_RNG)
             u = have_u ? u_pre : philox_uniform(a.seed, (unsigned long long)((a.ray_id0 + b) * a.N + i));
         else
-            u = a.u[p];
+            u = __builtin_nontemporal_load(a.u + p);
         const float bin_diff = __fsub_rn(a.tbins[1], a.tbins[0]);
         t = __fadd_rn(__fmul_rn(bin_diff, u), a.tbins[i]);
     }
