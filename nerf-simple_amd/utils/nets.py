@@ -137,6 +137,28 @@ class Nerf(nn.Module):
         return out
 
 
+    def fp16_headroom(self, v):
+        """Largest hidden activation of the network on the query points v [P,6], as a fraction of the fp16
+        range (65504): the default precision='fp16' render needs this well below 1 (a trained NeRF sits
+        around 1e-4 .. 1e-3); use precision='bf16' otherwise.  Diagnostic: runs the bf16 training forward
+        once and scans the activations it saves (layers 0..9, post-ReLU / linear)."""
+        _lib.require_cuda_f32(v, "v")
+        lib = _lib.lib()
+        v = v.detach().contiguous()
+        P = v.shape[0]
+        if P == 0:
+            return 0.0
+        nbytes = int(lib.nerf_amd_train_activation_bytes(P))
+        bf16_bytes = 10 * ((P + 255) // 256) * 256 * 512            # the point-blocked bf16 region (nerf_amd.h)
+        acts = torch.zeros(nbytes, dtype=torch.uint8, device=v.device)
+        out = torch.empty((P, 4), dtype=torch.float32, device=v.device)
+        with torch.cuda.device(v.device):
+            _lib.check(lib.nerf_amd_mlp_forward_train_points(_lib.ptr(v), _lib.ptr(self.packed_weights(_lib.BF16)),
+                                                             _lib.ptr(out), _lib.ptr(acts), P, _lib.stream_ptr(v.device)),
+                       "nerf_amd_mlp_forward_train_points")
+        return float(acts[:bf16_bytes].view(torch.bfloat16).float().abs().max()) / 65504.0
+
+
 class CoarseNet(nn.Module):
     """Placeholder, as in the reference (utils/nets.py:45-46: hierarchical
     sampling is not implemented there)."""

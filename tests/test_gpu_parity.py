@@ -162,6 +162,21 @@ def test_mlp_hidden_activations_golden(dev, golden, synthetic, kind):
     assert scaled_err(out.cpu().numpy(), g["out"]) <= TOL[("bf16", kind)]
 
 
+def test_fp16_headroom(dev, oracle, synthetic):
+    """Nerf.fp16_headroom: the largest hidden activation (oracle h5 / h8 / h9 are among the scanned layers)
+    over the fp16 range -- the diagnostic that goes with the fp16 default."""
+    for kind in ("default", "structured"):
+        net = make_net(synthetic, dev, kind, "fp16")
+        v = synthetic.points_in_scene(700, seed=2)
+        with torch.no_grad():
+            _, hid = oracle.nerf_forward(synthetic.synthetic_state_dict(0, kind), v, return_hidden=True)
+        floor = max(float(h.abs().max()) for h in hid.values()) / 65504.0
+        got = net.fp16_headroom(v.to(dev))
+        print(kind, "fp16 headroom", got, "floor from h5/h8/h9", floor)
+        assert 0.97 * floor <= got < 1e-2          # far inside the range for both synthetic weight sets
+    assert make_net(synthetic, dev, "default", "fp16").fp16_headroom(torch.zeros(0, 6, device=dev)) == 0.0
+
+
 def test_mlp_repack_after_update(dev, oracle, synthetic):
     """The packed image is a derived cache: it must follow parameter updates."""
     net = make_net(synthetic, dev, "default", "fp32")
