@@ -94,7 +94,7 @@ if "c5g" in which or "c5" in which:   # config 5 through the captured hipGraphs 
         gt = torch.rand(4096, 3, device=dev)
         u = torch.rand(4096, N, device=dev)
         stepper = GraphedTrainStep(net, opt, 4096, N)
-        dt = timed(lambda: stepper.step(rays, gt, u=u), warm=3, reps=10)
+        dt = timed(lambda: stepper.step(rays, gt, u=u), warm=20, reps=500)
         s = 4096 * N
         print(json.dumps({"config": f"5: train step 4096 rays x {N} bf16, hipGraph replay (fwd+bwd+FusedAdam+repack)",
                           "ms": dt * 1e3, "ray_samples_per_s": s / dt, "tflops_fwd_bwd(3x)": 3 * s * FLOP / dt / 1e12}))
