@@ -7,9 +7,12 @@
 //   * two stacked 16-row accumulator tiles (2q, 2q+1), bias-initialised, ReLU'd and converted
 //     pairwise, ARE the B fragment of the next layer's k-step q (32 features): activations never
 //     leave the registers;
-//   * weights stream L2 -> LDS by LDS-DMA in chunks of four 16-row tiles, double buffered, one
-//     barrier per chunk; one weight fragment read from LDS (16 rows x 32 k, 1 KiB) feeds two
-//     MFMAs (the two column blocks);
+//   * weights stream L2 -> LDS by LDS-DMA in chunks of four 16-row tiles (eight for the K = 64 first
+//     layer; 38 chunks per tile), double buffered, one barrier per chunk; one weight fragment read
+//     from LDS (16 rows x 32 k, 1 KiB) feeds two MFMAs (the two column blocks);
+//   * the chunk barrier sits three fragments before the END of a chunk and the next chunk's first
+//     fragments are requested right behind it, so no chunk starts with an LDS round trip; the next
+//     chunk's DMA pieces go out one per four MFMAs (chunk_step);
 //   * the sigma head rides as row 256 of the layers_2 product, the rgb head is one 16-row tile;
 //   * a workgroup = 8 waves = a 256-point tile, persistent over tiles;
 //   * COMP (the render path): compositing (utils/rendering.py:47-85) runs in the same launch.  A

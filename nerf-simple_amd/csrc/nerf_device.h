@@ -46,7 +46,8 @@ struct MlpArgs {
 // ---- chunk barrier of the MLP kernels --------------------------------------------
 // Loads, LDS-DMA and stores share vmcnt on gfx9-family parts and retire in issue order, so
 // "this wave's DMA pieces have landed" is vmcnt(N) with N = the vector-memory instructions the
-// wave issued AFTER its DMA pieces in this chunk (activation / dY / mask stores, mask loads).
+// wave issued between its (last) DMA piece of this chunk and the wait (activation / dY / mask stores,
+// mask loads).
 // Waiting for vmcnt(0) instead -- which __syncthreads() also does through its release fence --
 // stalls every chunk on the round trip of the stores just issued.  N is a compile-time count;
 // tests/test_library_cpu.py::test_counted_vmcnt_waits checks it against the generated ISA.
