@@ -281,6 +281,9 @@ def run_render(args):
                        "rays": n_rays, "samples_per_ray": N_SAMPLES, "rays_per_launch": nr,
                        "launches_per_step": 1 if nws == 0 else 2,
                        "jitter": "device counter RNG", "weights": "synthetic_state_dict(0,'structured')",
+                       "operands": {"fp16": "fp16 MFMA operands, fp32 accumulate (same dense peak as bf16; the 16-bit type that "
+                                            "meets the 0.05 dB PSNR target on these weights: DESIGN.md section 2)",
+                                    "bf16": "bf16 MFMA operands, fp32 accumulate", "fp32": "exact-f32 MFMA"}[args.precision],
                        "parallelism": f"rays sharded x{world}" + (" + all_gather of [rgb,disp]" if world > 1 else "")},
             "ranks": seen,
             "roofline": {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak / 1e12,
