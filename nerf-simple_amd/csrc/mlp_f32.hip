@@ -93,10 +93,20 @@ struct Stage {
     }
 };
 
+// The first AHEAD weight fragment groups and the bias vector of the chunk that runs next, read right behind
+// the barrier that publishes its buffer.  That barrier sits TAIL fragment groups BEFORE the end of a chunk
+// (as in mlp_bf16_16.hip): the staged weights are written to LDS there, and the LDS round trip of the next
+// chunk's first reads is covered by this chunk's last 4 * TAIL MFMAs instead of idling the matrix pipe at
+// each of the 154 chunk starts of a tile.
+struct WFrag {
+    f32x4 a[2];
+    f32x4 bias;
+};
+
 // one chunk = 16-row output tile T of layer L
 template <int L, int T>
 __device__ __forceinline__ void chunk_step(const Ctx& c, const float (&in)[64], float (&out)[64],
-                                           float& sigma, float (&rgb)[3]) {
+                                           float& sigma, float (&rgb)[3], WFrag& wf) {
     constexpr LayerDesc D = layer_desc(L);
     constexpr int Q_CHAIN = D.chain_k / 16;         // groups of 4 k-steps from the chain
     constexpr int Q_EXTRA = D.extra_slots / 16;
@@ -104,20 +114,38 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, const float (&in)[64], 
     constexpr int CC = chunk_first(L) + T;
     constexpr int WB = LDS_W0 + (CC & 1) * LDS_WBUF;
     constexpr int AHEAD = 2;
-    constexpr int BIAS_OFF = LDS_BIAS + (f32_bias_off(L) + 16 * T) * 4;
+    // the chunk that runs next (cyclic over tiles)
+    constexpr int NCC = (CC + 1) % F32_NUM_CHUNKS;
+    constexpr int NL = chunk_layer(NCC);
+    constexpr int NQ = layer_desc(NL).chain_k / 16 + layer_desc(NL).extra_slots / 16;
+    constexpr int NWB = LDS_W0 + (NCC & 1) * LDS_WBUF;
+    constexpr int NBIAS_OFF = LDS_BIAS + (f32_bias_off(NL) + 16 * (NCC - chunk_first(NL))) * 4;
+    constexpr int TAIL = 2;
+    constexpr int QB = Q > TAIL + AHEAD ? Q - TAIL : Q;       // barrier in front of group QB (Q: at the end)
 
     Stage<CC> st;
     st.load(c);
+    auto publish_and_prefetch = [&]() {
+        // every read of this chunk's buffer has been issued at least AHEAD groups ago; the other buffer was last
+        // read in front of the previous chunk's barrier: it can take the next chunk's weights now
+        st.store(c);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < AHEAD && q < NQ; ++q) wf.a[q] = lds_load<f32x4>(c.b_wread, NWB + q * 1024);
+        wf.bias = lds_load<f32x4>(c.b_bias, NBIAS_OFF);
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     // register i of lane group g is row 16T + 4g + i
-    f32x4 acc0 = lds_load<f32x4>(c.b_bias, BIAS_OFF);
+    f32x4 acc0 = wf.bias;
     f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
     f32x4 a[AHEAD];
 #pragma unroll
-    for (int q = 0; q < AHEAD && q < Q; ++q) a[q] = lds_load<f32x4>(c.b_wread, WB + q * 1024);
+    for (int q = 0; q < AHEAD && q < Q; ++q) a[q] = wf.a[q];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
+        if (q == QB) publish_and_prefetch();
         const f32x4 aq = a[q % AHEAD];
         if (q + AHEAD < Q) a[q % AHEAD] = lds_load<f32x4>(c.b_wread, WB + (q + AHEAD) * 1024);
         f32x4 bq;
@@ -144,20 +172,19 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, const float (&in)[64], 
 #pragma unroll
         for (int i = 0; i < 4; ++i) out[4 * T + i] = D.relu ? fmaxf(r[i], 0.f) : r[i];
     }
-    st.store(c);
-    __syncthreads();
+    if constexpr (QB == Q) publish_and_prefetch();
 }
 
 template <int L, int... Ts>
 __device__ __forceinline__ void run_layer_seq(const Ctx& c, const float (&in)[64], float (&out)[64],
-                                              float& sigma, float (&rgb)[3],
+                                              float& sigma, float (&rgb)[3], WFrag& wf,
                                               std::integer_sequence<int, Ts...>) {
-    (chunk_step<L, Ts>(c, in, out, sigma, rgb), ...);
+    (chunk_step<L, Ts>(c, in, out, sigma, rgb, wf), ...);
 }
 template <int L>
 __device__ __forceinline__ void run_layer(const Ctx& c, const float (&in)[64], float (&out)[64],
-                                          float& sigma, float (&rgb)[3]) {
-    run_layer_seq<L>(c, in, out, sigma, rgb, std::make_integer_sequence<int, f32_mt(L)>{});
+                                          float& sigma, float (&rgb)[3], WFrag& wf) {
+    run_layer_seq<L>(c, in, out, sigma, rgb, wf, std::make_integer_sequence<int, f32_mt(L)>{});
 }
 
 __device__ __forceinline__ float enc_exact(float x, int idx) {
@@ -225,19 +252,19 @@ struct RingSamples {                         // a ray's samples in the workgroup
 };
 
 // one tile's 11 layers; leaves rgb / sigma of the wave's 16 points in lane group 0
-__device__ __forceinline__ void run_tile(const Ctx& c, float& sigma, float (&rgb)[3]) {
+__device__ __forceinline__ void run_tile(const Ctx& c, float& sigma, float (&rgb)[3], WFrag& wf) {
     float A[64], B[64];
-    run_layer<0>(c, A, A, sigma, rgb);
-    run_layer<1>(c, A, B, sigma, rgb);
-    run_layer<2>(c, B, A, sigma, rgb);
-    run_layer<3>(c, A, B, sigma, rgb);
-    run_layer<4>(c, B, A, sigma, rgb);
-    run_layer<5>(c, A, B, sigma, rgb);
-    run_layer<6>(c, B, A, sigma, rgb);
-    run_layer<7>(c, A, B, sigma, rgb);
-    run_layer<8>(c, B, A, sigma, rgb);
-    run_layer<9>(c, A, B, sigma, rgb);
-    run_layer<10>(c, B, A, sigma, rgb);
+    run_layer<0>(c, A, A, sigma, rgb, wf);
+    run_layer<1>(c, A, B, sigma, rgb, wf);
+    run_layer<2>(c, B, A, sigma, rgb, wf);
+    run_layer<3>(c, A, B, sigma, rgb, wf);
+    run_layer<4>(c, B, A, sigma, rgb, wf);
+    run_layer<5>(c, A, B, sigma, rgb, wf);
+    run_layer<6>(c, B, A, sigma, rgb, wf);
+    run_layer<7>(c, A, B, sigma, rgb, wf);
+    run_layer<8>(c, B, A, sigma, rgb, wf);
+    run_layer<9>(c, A, B, sigma, rgb, wf);
+    run_layer<10>(c, B, A, sigma, rgb, wf);
 }
 
 template <bool RAYS, bool COMP>
@@ -268,6 +295,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_f32_kernel(Mlp
         st.store(c);
     }
     __syncthreads();
+    WFrag wf;                                   // chunk 0's first fragment groups and bias (chunk_step hands them on)
+    wf.a[0] = lds_load<f32x4>(c.b_wread, LDS_W0);
+    wf.a[1] = lds_load<f32x4>(c.b_wread, LDS_W0 + 1024);
+    wf.bias = lds_load<f32x4>(c.b_bias, LDS_BIAS + f32_bias_off(0) * 4);
 
     if constexpr (!COMP) {
         for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -275,7 +306,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_f32_kernel(Mlp
             asm volatile("" : "+s"(c.wave_goff));
             stage_inputs<RAYS>(c, a, tile_base, a.P, -1);
             float sigma, rgb[3];
-            run_tile(c, sigma, rgb);
+            run_tile(c, sigma, rgb, wf);
             // rows 0..2 (rgb) / row 256 (sigma) are registers 0..2 / 0 of lane group 0
             if (c.lane < 16) {
                 const long long p = tile_base + c.wave * 16 + c.lane;
@@ -297,7 +328,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_f32_kernel(Mlp
             asm volatile("" : "+s"(c.wave_goff));
             stage_inputs<true>(c, a, range_base + q_tile, range_base + n_pts, q_tile & (RING_PTS - 1));
             float sigma, rgb[3];
-            run_tile(c, sigma, rgb);
+            run_tile(c, sigma, rgb, wf);
             if (c.lane < 16) {
                 const int local = c.wave * 16 + c.lane;
                 if (q_tile + local < n_pts) {
