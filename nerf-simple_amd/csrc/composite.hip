@@ -113,16 +113,11 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_backward_kernel
                 ds[ch] = (1.0f - a) * delta * spd;       // d alpha / d sigma
                 tt[ch] = t; cc[ch] = c;
             }
-            float incl = fac;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const float up = __shfl_up(incl, off);
-                if (lane >= off) incl *= up;
-            }
-            float excl = __shfl_up(incl, 1);
-            if (lane == 0) excl = 1.0f;
-            al[ch] = a; fc[ch] = fac; Tt[ch] = carry * excl;
-            carry *= __shfl(incl, 63);
+            // the forward compositor's scan (composite_device.h): same tree, same rounded products
+            const float incl = nerf_composite::wave_scan_mul(fac);
+            const float excl = nerf_composite::dpp_move<0x138, 0xf>(1.0f, incl);          // wave_shr:1
+            al[ch] = a; fc[ch] = fac; Tt[ch] = __fmul_rn(carry, excl);
+            carry = __fmul_rn(carry, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63)));
             if (valid) {
                 depth += a * Tt[ch] * tt[ch]; accw += a * Tt[ch];
                 // the same ops as the forward compositor (composite_device.h), so rgb_out equals its rgb
@@ -138,7 +133,7 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_backward_kernel
           gb = g_rgb ? g_rgb[ray * 3 + 2] : 0.f;
     if (mse_target) {
         // loss = MSELoss(rgb, target) (train.py:52): d loss / d rgb = 2 (rgb - target) / (3 B), formed here
-        sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb);
+        sr = nerf_composite::wave_total(sr); sg = nerf_composite::wave_total(sg); sb = nerf_composite::wave_total(sb);
         gr = 2.0f * (sr - mse_target[ray * 3 + 0]) * mse_scale;
         gg = 2.0f * (sg - mse_target[ray * 3 + 1]) * mse_scale;
         gb = 2.0f * (sb - mse_target[ray * 3 + 2]) * mse_scale;

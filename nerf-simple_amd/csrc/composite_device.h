@@ -15,6 +15,34 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Cross-lane moves as DPP modifiers (VALU speed) instead of ds_bpermute round trips through the LDS
+// crossbar: row_shr:n inside each row of 16 lanes, row_bcast:15 / row_bcast:31 between rows.  A lane
+// with no source (or in a row ROW_MASK leaves out) receives `idle`, the identity of the caller's op.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float idle, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(idle), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// inclusive product scan over the 64 lanes; every product is one rounded multiply
+__device__ __forceinline__ float wave_scan_mul(float x) {
+    x = __fmul_rn(x, dpp_move<0x111, 0xf>(1.0f, x));      // row_shr:1
+    x = __fmul_rn(x, dpp_move<0x112, 0xf>(1.0f, x));      // row_shr:2
+    x = __fmul_rn(x, dpp_move<0x114, 0xf>(1.0f, x));      // row_shr:4
+    x = __fmul_rn(x, dpp_move<0x118, 0xf>(1.0f, x));      // row_shr:8
+    x = __fmul_rn(x, dpp_move<0x142, 0xa>(1.0f, x));      // row_bcast:15 -> rows 1, 3
+    x = __fmul_rn(x, dpp_move<0x143, 0xc>(1.0f, x));      // row_bcast:31 -> rows 2, 3
+    return x;
+}
+// sum over the 64 lanes as a wave-uniform value (the same tree with adds; lane 63 holds the total)
+__device__ __forceinline__ float wave_total(float x) {
+    x = __fadd_rn(x, dpp_move<0x111, 0xf>(0.f, x));
+    x = __fadd_rn(x, dpp_move<0x112, 0xf>(0.f, x));
+    x = __fadd_rn(x, dpp_move<0x114, 0xf>(0.f, x));
+    x = __fadd_rn(x, dpp_move<0x118, 0xf>(0.f, x));
+    x = __fadd_rn(x, dpp_move<0x142, 0xa>(0.f, x));
+    x = __fadd_rn(x, dpp_move<0x143, 0xc>(0.f, x));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
+}
+
 // ||d / ||d|| || as the reference computes it: dirs = rays[:,3:] / norm (rendering.py:37), then
 // torch.norm(dirs[..., None, :], dim=-1) inside volume_render (:62)
 __device__ __forceinline__ float unit_dir_norm(float d0, float d1, float d2, bool normalize) {
@@ -56,17 +84,11 @@ __device__ __forceinline__ void composite_ray(const Src& src, int N, int lane, f
             fac = __fadd_rn(__fsub_rn(1.0f, a), 1e-10f);
         }
         // inclusive product scan across the wave, shifted by one lane = exclusive cumprod (rendering.py:68)
-        float incl = fac;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const float up = __shfl_up(incl, off);
-            if (lane >= off) incl = __fmul_rn(incl, up);
-        }
-        float excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.0f;
+        const float incl = wave_scan_mul(fac);
+        const float excl = dpp_move<0x138, 0xf>(1.0f, incl);          // wave_shr:1
         const float T = __fmul_rn(carry, excl);
         const float wt = __fmul_rn(a, T);
-        carry = __fmul_rn(carry, __shfl(incl, 63));
+        carry = __fmul_rn(carry, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63)));
         if (valid) {
             // per-sample outputs are streamed (8 B per sample when requested): non-temporal stores
             if (o.alpha) __builtin_nontemporal_store(a, o.alpha + ray * N + i);
@@ -78,8 +100,8 @@ __device__ __forceinline__ void composite_ray(const Src& src, int N, int lane, f
             sa = __fadd_rn(sa, wt);
         }
     }
-    sr = wave_sum(sr); sg = wave_sum(sg); sb = wave_sum(sb);
-    sd = wave_sum(sd); sa = wave_sum(sa);
+    sr = wave_total(sr); sg = wave_total(sg); sb = wave_total(sb);
+    sd = wave_total(sd); sa = wave_total(sa);
     if (lane == 0) {
         const float q = __fdiv_rn(sd, sa);
         const float m = (q != q) ? q : fmaxf(1e-10f, q);   // torch.max propagates NaN
