@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Randomised shape sweeps on the GPU box, beyond what the test suite runs every round.
+
+    python tools/fuzz_gpu.py render     # 340 random (B, N <= 768, jitter mode) cases, three precisions:
+                                        # the fused render kernel == MLP launch + compositor launch, bit for bit
+    python tools/fuzz_gpu.py train      # 25 ragged (B, N) batches: fused training gradients vs the CPU oracle's
+                                        # fp32 autograd under the test suite's stated bounds (tests/test_gpu_training.py)
+
+Uses oracle/ as the checker, like the tests.  Batches of a few points can exceed the per-tensor bound on the two sigma
+tensors: with similar colours along a ray d loss / d sigma is a difference of nearly equal terms, and bf16 colour noise
+of 1e-3 is then tens of per cent of it (2 x 3 points: 15 % of sum |d sigma_i|); it averages out with the batch
+(DESIGN.md section 8).
+"""
+import sys
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def render():
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils import synthetic
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    lib = _lib.lib(); dev = torch.device("cuda:0")
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 70)).float()
+    allrays = camera_rays([pose], [100, 100, synthetic.focal_from_fov(100)]).float().contiguous().to(dev)
+    st = _lib.stream_ptr(dev)
+    rng = np.random.Generator(np.random.PCG64(7))
+    bad = 0
+    for prec in ("fp16", "bf16", "fp32"):
+        net = Nerf(precision=prec).to(dev); net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+        code = _lib.precision_code(prec); packed = net.packed_weights(code)
+        n_cases = 150 if prec != "fp32" else 40
+        for k in range(n_cases):
+            N = int(rng.integers(1, 769)); B = int(rng.integers(1, max(2, min(10000, 300000 // N))))
+            rays = allrays[:B].contiguous(); tb = torch.linspace(2, 6, N + 1).to(dev)
+            mode = k % 3
+            if mode == 0: jit, flags = None, 2
+            elif mode == 1: jit, flags = torch.rand(B, N, device=dev), 0
+            else: jit, flags = torch.sort(torch.rand(B, N, device=dev) * 4 + 2, dim=1).values.contiguous(), 1
+            raw, ts = torch.empty(B, N, 4, device=dev), torch.empty(B, N, device=dev)
+            _lib.check(lib.nerf_amd_mlp_forward_rays(_lib.ptr(rays), _lib.ptr(jit), _lib.ptr(tb), _lib.ptr(packed), code, flags, k, 3 * k, _lib.ptr(raw), _lib.ptr(ts), B, N, st), "a")
+            two = [torch.empty(s_, device=dev) for s_ in ((B, 3), (B,), (B, N), (B,), (B, N))]
+            _lib.check(lib.nerf_amd_volume_render_rays(_lib.ptr(raw), _lib.ptr(ts), _lib.ptr(rays), *[_lib.ptr(x) for x in two], B, N, st), "b")
+            one = [torch.full(s_, -7.0, device=dev) for s_ in ((B, 3), (B,), (B, N), (B,), (B, N))]
+            _lib.check(lib.nerf_amd_render_forward(_lib.ptr(rays), _lib.ptr(jit), _lib.ptr(tb), _lib.ptr(packed), code, flags, k, 3 * k, *[_lib.ptr(x) for x in one], None, B, N, st), "c")
+            torch.cuda.synchronize()
+            for a, b in zip(one, two):
+                if not bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all()):
+                    bad += 1; print("MISMATCH", prec, B, N, flags); break
+    print("sweep done, mismatches:", bad)
+
+
+
+def train():
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_training as T
+    from nerf_simple_amd.utils import synthetic
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("nerf_oracle", os.path.join(ROOT, "oracle", "nerf_oracle.py"))
+    oracle = importlib.util.module_from_spec(spec); spec.loader.exec_module(oracle)
+    dev = torch.device("cuda:0")
+    rng = np.random.Generator(np.random.PCG64(11))
+    bad = 0
+    shapes = [(1, 2), (1, 64), (2, 3), (3, 257), (1, 300), (5, 512), (100, 2)]
+    shapes += [(int(rng.integers(1, 60)), int(rng.integers(2, 131))) for _ in range(18)]
+    for B, N in shapes:
+        for kind in ("default",):
+            gen = torch.Generator().manual_seed(B * 1000 + N)
+            pose = torch.from_numpy(oracle.spherical_to_pose(4, -30, 0)).float()
+            side = int(np.ceil(np.sqrt(B)))
+            rays = oracle.camera_rays(pose, [side, side, synthetic.focal_from_fov(side)])[:B].contiguous()
+            gt = torch.rand(B, 3, generator=gen); u = torch.rand(B, N, generator=gen)
+            try:
+                loss, grads = T._fused_grads(dev, synthetic, kind, rays, gt, u, N)
+                fin = all(bool(torch.isfinite(torch.as_tensor(g)).all()) for g in (grads.values() if isinstance(grads, dict) else grads))
+                T._compare_with_oracle(oracle, synthetic, kind, rays, gt, u, N, loss, grads, f"{B}x{N}")
+                print(f"ok   {B:3d} x {N:3d}  P={B*N:5d} loss={loss:.5f} finite={fin}", flush=True)
+                if not fin: bad += 1
+            except AssertionError as e:
+                bad += 1; print(f"FAIL {B} x {N}: {str(e)[:200]}", flush=True)
+    print("fuzz done, failures:", bad)
+
+
+
+if __name__ == "__main__":
+    if len(sys.argv) != 2 or sys.argv[1] not in ("render", "train"):
+        sys.exit(__doc__)
+    {"render": render, "train": train}[sys.argv[1]]()
