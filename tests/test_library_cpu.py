@@ -208,3 +208,17 @@ def test_counted_vmcnt_waits():
         assert sum(n for n, _ in stores.values()) >= (76 if src == "mlp_bf16_16.hip" else 152), (src, stores)
         for name, (n, offenders) in stores.items():
             assert not offenders, (src, name, offenders[:3])
+
+
+def test_stamp_tool_insertion_points():
+    """tools/stamp_tiles.py (the diagnostic build behind DESIGN.md section 5's cycles-per-phase table) matches
+    its insertion points in csrc/mlp_bf16_16.hip literally; this keeps them in step with the kernel source."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("stamp_tiles", os.path.join(root, "tools", "stamp_tiles.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src = mod.stamped_source()                         # SystemExit when a pattern is missing or ambiguous
+    assert src.count("STAMP(") == 19                   # the macro + 18 stamps
+    shipped = open(os.path.join(root, "nerf-simple_amd", "csrc", "mlp_bf16_16.hip")).read()
+    assert "s_memtime" not in shipped and "STAMP" not in shipped     # the shipped kernel carries none

@@ -73,16 +73,9 @@ extern "C" int NERF_LAUNCH('''),
 ]
 
 
-def build():
-    if os.path.isdir(SCRATCH):
-        shutil.rmtree(SCRATCH)
-    os.makedirs(SCRATCH)
-    shutil.copytree(os.path.join(ROOT, "nerf-simple_amd", "csrc"), os.path.join(SCRATCH, "csrc"),
-                    ignore=shutil.ignore_patterns("build", "*.so", "*.o"))
-    os.makedirs(os.path.join(ROOT, ".scratch", "include"), exist_ok=True)     # the Makefile's ../../include
-    shutil.copy(os.path.join(ROOT, "include", "nerf_amd.h"), os.path.join(ROOT, ".scratch", "include"))
-    path = os.path.join(SCRATCH, "csrc", "mlp_bf16_16.hip")
-    src = open(path).read()
+def stamped_source():
+    """mlp_bf16_16.hip with the stamps inserted; exits when an insertion point is not found exactly once."""
+    src = open(os.path.join(ROOT, "nerf-simple_amd", "csrc", "mlp_bf16_16.hip")).read()
     for old, new in PATCHES:
         if src.count(old) != 1:
             sys.exit(f"stamp_tiles: insertion point not found exactly once:\n{old}")
@@ -92,7 +85,19 @@ def build():
         if len(old) != 1:
             sys.exit(f"stamp_tiles: run_layer<{L}> call not found exactly once")
         src = src.replace(old[0] + "\n", old[0] + f"\n    STAMP({L + 2});\n")
-    open(path, "w").write(src)
+    return src
+
+
+def build():
+    src = stamped_source()
+    if os.path.isdir(SCRATCH):
+        shutil.rmtree(SCRATCH)
+    os.makedirs(SCRATCH)
+    shutil.copytree(os.path.join(ROOT, "nerf-simple_amd", "csrc"), os.path.join(SCRATCH, "csrc"),
+                    ignore=shutil.ignore_patterns("build", "*.so", "*.o"))
+    os.makedirs(os.path.join(ROOT, ".scratch", "include"), exist_ok=True)     # the Makefile's ../../include
+    shutil.copy(os.path.join(ROOT, "include", "nerf_amd.h"), os.path.join(ROOT, ".scratch", "include"))
+    open(os.path.join(SCRATCH, "csrc", "mlp_bf16_16.hip"), "w").write(src)
     subprocess.check_call(["make", "-C", os.path.join(SCRATCH, "csrc"), "-j8"], stdout=subprocess.DEVNULL)
     print("built", os.path.join(SCRATCH, "libnerf_amd.so"))
 
