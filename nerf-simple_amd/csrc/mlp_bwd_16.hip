@@ -190,6 +190,9 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
         for (int t = 0; t < NT; ++t) acc[cb][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
 
+    // register lifetimes against the MFMA write-after-read hazard nops, as in mlp_bf16_16.hip chunk_step
+    ex8 as_prev = a[0];
+    f32x4 c_prev = acc[0][0];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
 #pragma unroll
@@ -204,7 +207,10 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
                 ex8 bs;
                 if (ks < KS_CHAIN) bs = in[cb][ks < KS_CHAIN ? ks : 0];
                 else bs = (B == 0) ? st.bx_rgb[cb] : st.bx_sig[cb];
-                acc[cb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as, bs, acc[cb][t], 0, 0, 0);
+                const f32x4 c_old = acc[cb][t];
+                acc[cb][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as, bs, c_old, 0, 0, 0);
+                asm volatile("" :: "v"(c_prev));
+                c_prev = c_old;
                 if constexpr (PB >= 0) {
                     if (m >= PEND_M0 && m < PEND_M0 + 8 / PEND_PER) {
 #pragma unroll
@@ -223,8 +229,13 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            asm volatile("" :: "v"(as_prev));
+            as_prev = as;
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    asm volatile("" :: "v"(as_prev));
+    asm volatile("" :: "v"(c_prev));
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         st.pend[cb][0] = acc[cb][NT - 2];
