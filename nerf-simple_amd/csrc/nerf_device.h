@@ -141,7 +141,13 @@ __device__ __forceinline__ RaySample split_point(long long p, int N) {
 
 // the counter RNG's draw for (ray b, sample i) of this launch (FLAG_DEVICE_RNG)
 __device__ __forceinline__ float device_rng_uniform(const MlpArgs& a, RaySample rs) {
-    return philox_uniform(a.seed, (unsigned long long)((a.ray_id0 + rs.b) * a.N + rs.i));
+    // The seed passes through an empty asm so that the ten rounds' key schedule (k += const, wave-uniform)
+    // is recomputed here -- 20 scalar adds -- instead of being hoisted out of the persistent tile loop as
+    // 20 live SGPRs, which the fused render kernel could only keep by spilling them to VGPR lanes
+    // (v_writelane / v_readlane + hazard nops inside every Philox round).
+    unsigned long long seed = a.seed;
+    asm volatile("" : "+s"(seed));
+    return philox_uniform(seed, (unsigned long long)((a.ray_id0 + rs.b) * a.N + rs.i));
 }
 
 // u_pre: the point's device-RNG draw when the caller already has it (have_u), see mlp_bf16_16.hip stage_inputs
