@@ -4,7 +4,9 @@ HIP-event timing of the kernel alone on the 800x800x128 workload (cdna_hip_progr
 
     python tools/ab_bench.py [--rounds 8] VARIANT [VARIANT ...]
 
-VARIANT = [path/to/lib.so:]precision[:fused], e.g.  bf16  fp16  /tmp/old/libnerf_amd.so:bf16
+VARIANT = [path/to/lib.so:]precision[:fused][:u], e.g.  bf16  fp16:fused  /tmp/old/libnerf_amd.so:bf16
+(":u" = jitter read from a [B,N] buffer in HBM, as in the reference-compatible default of render_nerf,
+instead of the counter RNG)
 Without a path the in-tree library is used.  A second build to compare against is made by
 checking the other revision out into a scratch directory and running `make -C nerf-simple_amd/csrc`
 there; nothing in the shipped sources is switched by environment variables or macros.
@@ -40,12 +42,16 @@ raw = torch.empty(B, N, 4, device=dev)
 ts = torch.empty(B, N, device=dev)
 pixels = torch.empty(B, 4, device=dev)
 tb = torch.linspace(2, 6, N + 1).to(dev)
+u_buf = torch.rand(B, N, device=dev)
 vp, i64, i32, u32, u64 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64
 
 
 class Variant:
     def __init__(self, spec):
         parts = spec.split(":")
+        self.given_u = parts[-1] == "u"
+        if self.given_u:
+            parts = parts[:-1]
         self.fused = parts[-1] == "fused"
         if self.fused:
             parts = parts[:-1]
@@ -67,13 +73,14 @@ class Variant:
         self.times = []
 
     def run(self):
+        jit, flags = (_lib.ptr(u_buf), 0) if self.given_u else (None, 2)
         if self.fused:
             _lib.check(self.h.nerf_amd_render_pixels_forward(
-                _lib.ptr(rays), None, _lib.ptr(tb), _lib.ptr(self.packed), self.precision, 2, 1234, 0,
+                _lib.ptr(rays), jit, _lib.ptr(tb), _lib.ptr(self.packed), self.precision, flags, 1234, 0,
                 _lib.ptr(pixels), None, B, N, _lib.stream_ptr(dev)), "render_pixels")
         else:
             _lib.check(self.h.nerf_amd_mlp_forward_rays(
-                _lib.ptr(rays), None, _lib.ptr(tb), _lib.ptr(self.packed), self.precision, 2, 1234, 0,
+                _lib.ptr(rays), jit, _lib.ptr(tb), _lib.ptr(self.packed), self.precision, flags, 1234, 0,
                 _lib.ptr(raw), _lib.ptr(ts), B, N, _lib.stream_ptr(dev)), "mlp")
 
 
