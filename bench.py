@@ -82,9 +82,22 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    # wait for all ranks; a rank that dies takes the others down with it (they would wait for it in a collective)
+    rc, live = 0, list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                rc = max(rc, abs(code))
+    for p in live:
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
     sys.exit(rc)
 
 
