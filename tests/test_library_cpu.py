@@ -210,6 +210,36 @@ def test_counted_vmcnt_waits():
             assert not offenders, (src, name, offenders[:3])
 
 
+def test_inference_kernels_have_few_hazard_nops():
+    """csrc/mlp_bf16_16.hip chunk_step keeps a weight fragment and an accumulator alive a little past
+    their last MFMA so that the registers coming free are not operands of the MFMA just issued: the
+    hazard recognizer then has no write-after-read wait states to insert (617 s_nop per tile before,
+    74 now).  A compiler or source change that brings them back costs 1-2 %."""
+    import re
+    import shutil
+    import sys
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    try:
+        import check_vmcnt
+    finally:
+        sys.path.pop(0)
+    asm = check_vmcnt.assemble(os.path.join(root, "nerf-simple_amd", "csrc", "mlp_bf16_16.hip"))
+    seen = 0
+    for name, body in check_vmcnt.kernels_of(asm).items():
+        if "ILb1ELb1ELb0EE" in name:                    # the training forward: its stores bring their own
+            continue
+        lines = body if isinstance(body, list) else body.split("\n")
+        mfma = [i for i, ln in enumerate(lines) if re.match(r"\s+v_mfma", ln)]
+        assert len(mfma) == 2344, (name, len(mfma))
+        nops = [ln for ln in lines[mfma[0]:mfma[-1] + 1] if re.match(r"\s+s_nop", ln)]
+        assert len(nops) <= 150, (name, len(nops))
+        seen += 1
+    assert seen == 3
+
+
 def test_stamp_tool_insertion_points():
     """tools/stamp_tiles.py (the diagnostic build behind DESIGN.md section 5's cycles-per-phase table) matches
     its insertion points in csrc/mlp_bf16_16.hip literally; this keeps them in step with the kernel source."""
