@@ -221,14 +221,18 @@ def render_poses(net, poses, cam_params, batch_size, savepath='', *, N=128, tn=2
     """Render one image per pose (reference utils/rendering.py:116-153).
     poses: list of [4,4] float tensors; cam_params [H,W,f].  Returns
     (rgb_imgs, disp_imgs): lists of numpy [H,W,3] / [H,W].  The reference's mp4
-    writer (cv2, :155-160) is out of scope; ``savepath`` is accepted and ignored."""
-    from .xyz import camera_rays
+    writer (cv2, :155-160) is out of scope; ``savepath`` is accepted and ignored.
+
+    The reference builds the ray table of every pose on the CPU (:129-134) and moves it to the GPU batch
+    by batch; at 800x800 that table takes 0.2 s per pose on 8 cores -- three times the render -- and
+    24 B per ray of PCIe.  Here each pose's rays come from the device generator (generate_rays, N1:
+    the same table to the fma rounding of the 3-term rotation, 2.4e-7 absolute)."""
     H, W = cam_params[0], cam_params[1]
     dev = next(net.parameters()).device
-    rays_all = camera_rays(poses, cam_params).to(dev)
     rgb_imgs, disp_imgs = [], []
     for i in range(len(poses)):
-        rays = rays_all[i * H * W:(i + 1) * H * W]
+        pose = poses[i].detach().cpu() if torch.is_tensor(poses[i]) else poses[i]
+        rays = generate_rays(pose, cam_params, dev)
         ui = None if u is None else u[i * H * W:(i + 1) * H * W]
         rgb, disp = _render_batched(rays, net, batch_size, N, tn, tf, ui, progress,
                                     id_base=i * H * W, **kw)
