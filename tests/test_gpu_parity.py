@@ -695,6 +695,44 @@ def test_render_image_dropin(dev, golden, synthetic, oracle):
     assert scaled_err(disp.reshape(-1).numpy(), g["disp"]) <= F32_TOL
 
 
+def test_render_poses_several_poses(dev, synthetic, oracle):
+    """render_poses over several poses (utils/rendering.py:116-153): image i is the render of pose i's device-generated
+    rays with rows [i*H*W, (i+1)*H*W) of ``u``; with the counter RNG the jitter is indexed by the global ray id
+    i*H*W + pixel, so two images of the SAME pose differ, and the whole call is reproducible; with the default jitter
+    the poses consume one continuous torch.rand stream, image after image."""
+    from nerf_simple_amd.utils.rendering import render_poses, render_view
+    H = W = 24
+    N = 16
+    cam = [H, W, synthetic.focal_from_fov(W)]
+    poses = [torch.from_numpy(oracle.spherical_to_pose(4, -30, phi)).float() for phi in (0.0, 90.0, 0.0)]
+    net = make_net(synthetic, dev, "structured", "fp32")
+    u = torch.rand(3 * H * W, N, generator=torch.Generator().manual_seed(4))
+    rgbs, disps = render_poses(net, poses, cam, batch_size=250, N=N, u=u.to(dev))
+    assert len(rgbs) == 3 and rgbs[0].shape == (H, W, 3) and disps[0].shape == (H, W)
+    with torch.no_grad():
+        for i, pose in enumerate(poses):
+            px = render_view(net, pose, cam, N=N, u=u[i * H * W:(i + 1) * H * W].to(dev)).cpu().numpy()
+            assert np.array_equal(px[:, :3].reshape(H, W, 3), rgbs[i]) and np.array_equal(px[:, 3].reshape(H, W), disps[i])
+    a, _ = render_poses(net, poses, cam, batch_size=250, N=N, device_rng=True, seed=9)
+    b, _ = render_poses(net, poses, cam, batch_size=576, N=N, device_rng=True, seed=9)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))              # reproducible, independent of the batch size
+    assert not np.array_equal(a[0], a[2])                                # same pose, other global ray ids: other jitter
+    saved = torch.get_rng_state()
+    try:
+        torch.manual_seed(21)
+        c, _ = render_poses(net, poses, cam, batch_size=250, N=N)        # the reference's default: torch's CPU generator
+        torch.manual_seed(21)
+        u_ref = torch.rand(3 * H * W, N)                                 # the same stream in one draw
+        after = torch.get_rng_state()
+        d, _ = render_poses(net, poses, cam, batch_size=250, N=N, u=u_ref.to(dev))
+        assert all(np.array_equal(x, y) for x, y in zip(c, d))
+        torch.manual_seed(21)
+        render_poses(net, poses, cam, batch_size=250, N=N)
+        assert torch.equal(torch.get_rng_state(), after)                 # and the generator ends where torch's draw does
+    finally:
+        torch.set_rng_state(saved)
+
+
 def test_reference_rand_is_torch_rand(dev, oracle):
     """A1: the reference's jitter `torch.rand(B, N)` on the CPU default generator
     (utils/rendering.py:28-30) continued on the GPU (csrc/host_rng.hip): bit-identical values from
