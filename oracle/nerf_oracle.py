@@ -276,6 +276,34 @@ def adam_step(sd, grads, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, step=1, state=No
     return new_sd, new_state
 
 
+def train_loop(sd, rays_table, gt_table, batch_size, N, num_iters, lr_init, lr_final, seed, decay_iters=None,
+               checkpoints=(), on_checkpoint=None):
+    """The loop body of train.py:45-57 on a ray table: per iteration ``randperm(n)[:batch_size]`` (RayGenerator.select,
+    utils/dataload.py:150-153), render_nerf at N samples (its one torch.rand(B,N) from the same CPU stream), MSELoss,
+    backward, torch.optim.Adam(lr=5e-4 hard-coded, train.py:43) step, lr *= decay with
+    decay = exp(log(lr_final / lr_init) / decay_iters) (train.py:36-39).  torch's CPU generator is seeded once.
+    Returns (losses [num_iters], final params); ``on_checkpoint(i, params)`` is called after iteration i in checkpoints."""
+    decay = np.exp(np.log(lr_final / lr_init) / (decay_iters or num_iters))
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    opt = torch.optim.Adam(list(params.values()), lr=5e-4)
+    losses = []
+    torch.manual_seed(seed)
+    for i in range(num_iters):
+        ray_ids = torch.randperm(rays_table.size(0))[:batch_size]
+        rays, gt = rays_table[ray_ids, :], gt_table[ray_ids, :]
+        opt.zero_grad()
+        rgb, _, _, _, _ = render_nerf(rays, params, N)
+        loss = F.mse_loss(rgb, gt)
+        loss.backward()
+        opt.step()
+        for pg in opt.param_groups:
+            pg["lr"] = pg["lr"] * decay
+        losses.append(loss.detach())
+        if on_checkpoint is not None and i + 1 in checkpoints:
+            on_checkpoint(i + 1, params)
+    return torch.stack(losses), {k: p.detach() for k, p in params.items()}
+
+
 # --------------------------------------------------------------------------
 # torch's CPU uniform stream (the jitter of reference utils/rendering.py:28-30), restated
 # --------------------------------------------------------------------------

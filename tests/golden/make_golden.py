@@ -19,7 +19,17 @@ Fixtures:
   G4 render_<kind>.npz render_nerf end-to-end, 256 rays x N in {32,64,128,192}
   G5 image_<kind>.npz  config-1 full 100x100 image, N=32 (clipped rgb, disp); image_u.npz = the jitter
   G6 train.npz         64 rays x 64 samples: loss, grads, params after one Adam step
+  G6b train_n128.npz   the same capture at the reference's own sample count Nf = 128 (configs/lego.yaml:6)
+  G6c train_cfg.npz    the reference's real step shape: 4096 rays x 128 samples (configs/lego.yaml:6,12) drawn from
+                       the G8 dataset, plus the reference's own minibatch gradient noise (4 independent batches)
   G7 camera.npz        rays_single_cam / spherical_to_pose / poses_to_render
+  G8 trajectory.npz    the training loop body of train.py:45-57 run for 60 iterations (randperm ray selection,
+                       render_nerf at Nf = 128, MSELoss, Adam, lr *= decay) on a synthetic two-view dataset: loss per
+                       step, parameters at steps 1 / 10 / 60, validation MSE; the same for three more seeds (the
+                       reference's own run-to-run spread); dataset.npz = the dataset's target colours
+
+    python tests/golden/make_golden.py            # everything
+    python tests/golden/make_golden.py g6c g8     # only the named fixtures
 """
 import os
 import sys
@@ -52,7 +62,7 @@ def ref_net(sd):
 
 
 def np_(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()          # a copy: .numpy() alone aliases live parameters (G8 stores mid-run)
 
 
 def save(name, **arrs):
@@ -218,6 +228,180 @@ def g6_train():
     save("train.npz", **out)
 
 
+def _store_grads(out, net):
+    for k, p in net.named_parameters():
+        g = p.grad
+        out[f"gnorm/{k}"] = np_(g.norm())
+        if g.numel() <= 4096:
+            out[f"grad/{k}"] = np_(g)
+        else:
+            out[f"gradc/{k}"] = np_(g[:16, :16])
+
+
+def _store_params(out, net, tag="post"):
+    for k, p in net.named_parameters():
+        if p.numel() <= 4096:
+            out[f"{tag}/{k}"] = np_(p)
+        else:
+            out[f"{tag}c/{k}"] = np_(p[:16, :16])
+
+
+def g6b_train_n128():
+    """G6 at Nf = 128, the sample count the reference trains with (train.py:51, configs/lego.yaml:6)."""
+    sd = synthetic.synthetic_state_dict(0, "default")
+    net = rnets.Nerf()
+    net.load_state_dict(sd, strict=True)
+    rays_img, _, _ = _cam_rays(100, 100)
+    idx = torch.randperm(10000, generator=torch.Generator().manual_seed(16))[:64]
+    rays = rays_img[idx].contiguous()
+    gt = torch.rand(64, 3, generator=torch.Generator().manual_seed(17))
+    N = 128
+    torch.manual_seed(166)
+    u = torch.rand(64, N)
+    torch.manual_seed(166)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    opt.zero_grad()
+    rgb, _, _, _, _ = rrend.render_nerf(rays, net, N)
+    loss = torch.nn.MSELoss()(rgb, gt)
+    loss.backward()
+    out = {"rays": np_(rays), "gt": np_(gt), "u": np_(u), "N": N, "loss": np_(loss), "rgb": np_(rgb)}
+    _store_grads(out, net)
+    opt.step()
+    _store_params(out, net)
+    save("train_n128.npz", **out)
+
+
+# ---- the synthetic dataset of G6c / G8 -------------------------------------------------------------
+DATASET_VIEWS = (0.0, 40.0)         # azimuths of the two 64x64 training views
+DATASET_HW = 64
+DATASET_SEED = 800
+
+
+def _dataset():
+    """Ray table [8192,6] of two 64x64 views (as utils/dataload.py:114-129 builds one per split) and its target
+    colours: the reference's own render of the 'structured' weights (the teacher), N = 128, clipped like
+    render_poses clips (utils/rendering.py:146)."""
+    teacher = ref_net(synthetic.synthetic_state_dict(0, "structured"))
+    rays = torch.cat([_cam_rays(DATASET_HW, DATASET_HW, phi)[0] for phi in DATASET_VIEWS]).contiguous()
+    torch.manual_seed(DATASET_SEED)
+    with torch.no_grad():
+        gts = []
+        for v in range(len(DATASET_VIEWS)):
+            n = DATASET_HW * DATASET_HW
+            rgb = rrend.render_nerf(rays[v * n:(v + 1) * n], teacher, 128)[0]
+            gts.append(torch.clip(rgb, torch.tensor(0.), torch.tensor(1.)))
+    return rays, torch.cat(gts)
+
+
+def _minibatch_std(grad_sets):
+    """Relative sampling deviation of the reference's minibatch gradient, per tensor: sample standard deviation of
+    the M batch gradients around their mean, over the norm of the mean."""
+    out = {}
+    M = len(grad_sets)
+    for k in grad_sets[0]:
+        stack = torch.stack([g[k] for g in grad_sets]).double()
+        mean = stack.mean(0)
+        dev = ((stack - mean) ** 2).sum() / (M - 1)
+        out[k] = float(torch.sqrt(dev) / mean.norm())
+    return out
+
+
+def g6c_train_config(rays_tab, gt_tab):
+    """One step at the reference's real shape (batch_size 4096, Nf 128: configs/lego.yaml:6,12) on the G8
+    dataset, ray selection as RayGenerator.select does it (utils/dataload.py:150-153); then the same step on
+    three more independent selections: the spread of the four gradients is the reference's own minibatch noise."""
+    sd = synthetic.synthetic_state_dict(0, "default")
+    B, N = 4096, 128
+    out, grad_sets = {}, []
+    for j, seed in enumerate((300, 301, 302, 303)):
+        net = rnets.Nerf()
+        net.load_state_dict(sd, strict=True)
+        opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+        torch.manual_seed(seed)
+        ray_ids = torch.randperm(rays_tab.size(0))[:B]
+        rays, gt = rays_tab[ray_ids, :], gt_tab[ray_ids, :]
+        opt.zero_grad()
+        rgb, _, _, _, _ = rrend.render_nerf(rays, net, N)
+        loss = torch.nn.MSELoss()(rgb, gt)
+        loss.backward()
+        grad_sets.append({k: p.grad.detach().clone() for k, p in net.named_parameters()})
+        if j == 0:
+            out.update({"seed": seed, "B": B, "N": N, "ray_ids": np_(ray_ids), "loss": np_(loss), "rgb": np_(rgb)})
+            _store_grads(out, net)
+            opt.step()
+            _store_params(out, net)
+        out[f"loss_batch{j}"] = np_(loss)
+    for k, v in _minibatch_std(grad_sets).items():
+        out[f"mbstd/{k}"] = np.float64(v)
+    save("train_cfg.npz", **out)
+
+
+G8_SEEDS = (88, 89, 90, 91)
+G8_B, G8_N, G8_K = 256, 128, 60
+G8_LR_INIT, G8_LR_FINAL = 5e-4, 1e-4
+G8_CHECKPOINTS = (1, 10, 60)
+G8_VAL_SEED = 801
+
+
+def g8_trajectory(rays_tab, gt_tab):
+    """train.py:45-57 for K iterations, per seed: ray_ids = randperm(n)[:B] -> render_nerf(rays, net, Nf) ->
+    MSELoss -> backward -> Adam.step -> lr *= decay.  torch's CPU generator is seeded once per run; the ray
+    selection and the jitter of every step come from that one stream, as in the reference."""
+    sd = synthetic.synthetic_state_dict(0, "default")
+    decay = np.exp(np.log(G8_LR_FINAL / G8_LR_INIT) / G8_K)           # train.py:36-39
+    val_rays, val_gt = rays_tab[::16].contiguous(), gt_tab[::16].contiguous()
+    out = {"seeds": np.asarray(G8_SEEDS), "B": G8_B, "N": G8_N, "K": G8_K, "lr_init": G8_LR_INIT,
+           "lr_final": G8_LR_FINAL, "decay": np.float64(decay), "checkpoints": np.asarray(G8_CHECKPOINTS),
+           "val_seed": G8_VAL_SEED, "val_stride": 16}
+
+    def val_mse(net):
+        st = torch.get_rng_state()
+        torch.manual_seed(G8_VAL_SEED)                                # u_val = the first torch.rand(512, N) of this seed
+        with torch.no_grad():
+            rgb = rrend.render_nerf(val_rays, net, G8_N)[0]
+        torch.set_rng_state(st)
+        return np_(torch.mean((rgb - val_gt) ** 2))
+
+    grad_sets = []
+    for seed in G8_SEEDS:
+        net = rnets.Nerf()
+        net.load_state_dict(sd, strict=True)
+        criterion = torch.nn.MSELoss()
+        optimizer = torch.optim.Adam(net.parameters(), lr=5e-4)
+        losses, lrs, vals = [], [], [val_mse(net)]
+        torch.manual_seed(seed)
+        for i in range(G8_K):
+            ray_ids = torch.randperm(rays_tab.size(0))[:G8_B]
+            rays, gt = rays_tab[ray_ids, :], gt_tab[ray_ids, :]
+            optimizer.zero_grad()
+            rgb, _, _, _, _ = rrend.render_nerf(rays, net, G8_N)
+            loss = criterion(rgb, gt)
+            loss.backward()
+            if i == 0:
+                grad_sets.append({k: p.grad.detach().clone() for k, p in net.named_parameters()})
+                if seed == G8_SEEDS[0]:
+                    out["ray_ids0"] = np_(ray_ids)
+                    _store_grads(out, net)
+            lrs.append(optimizer.param_groups[0]["lr"])
+            optimizer.step()
+            for p in optimizer.param_groups:
+                p["lr"] = p["lr"] * decay
+            losses.append(np_(loss))
+            if i + 1 in G8_CHECKPOINTS:
+                vals.append(val_mse(net))
+                if seed == G8_SEEDS[0]:
+                    _store_params(out, net, tag=f"step{i + 1}")
+        out[f"loss/{seed}"] = np.asarray(losses, dtype=np.float32)
+        out[f"val/{seed}"] = np.asarray(vals, dtype=np.float32)       # at steps 0 and G8_CHECKPOINTS
+        if seed == G8_SEEDS[0]:
+            out["lr"] = np.asarray(lrs, dtype=np.float64)
+            out["rng_next"] = np_(torch.rand(4))                      # the stream position after the run
+        print(f"  G8 seed {seed}: loss {float(losses[0]):.5f} -> {float(losses[-1]):.5f}, val {[float(v) for v in vals]}")
+    for k, v in _minibatch_std(grad_sets).items():
+        out[f"mbstd/{k}"] = np.float64(v)
+    save("trajectory.npz", **out)
+
+
 def g7_camera():
     f = synthetic.focal_from_fov(100)
     d = rxyz.rays_single_cam([100, 100, f])
@@ -231,11 +415,32 @@ def g7_camera():
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    g1_encode()
-    g3_composite()
-    g7_camera()
+    which = set(a.lower() for a in sys.argv[1:])
+
+    def want(name):
+        return not which or name in which
+
+    if want("g1"):
+        g1_encode()
+    if want("g3"):
+        g3_composite()
+    if want("g7"):
+        g7_camera()
     for kind in ("default", "structured"):
-        g2_mlp(kind)
-        g4_render(kind)
-        g5_image(kind)
-    g6_train()
+        if want("g2"):
+            g2_mlp(kind)
+        if want("g4"):
+            g4_render(kind)
+        if want("g5"):
+            g5_image(kind)
+    if want("g6"):
+        g6_train()
+    if want("g6b"):
+        g6b_train_n128()
+    if want("g6c") or want("g8"):
+        rays_tab, gt_tab = _dataset()
+        save("dataset.npz", gt=np_(gt_tab), views=np.asarray(DATASET_VIEWS), hw=DATASET_HW, seed=DATASET_SEED)
+        if want("g6c"):
+            g6c_train_config(rays_tab, gt_tab)
+        if want("g8"):
+            g8_trajectory(rays_tab, gt_tab)
