@@ -21,10 +21,19 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment is used as given.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      the dominant kernel against its roofline, duration from HIP events on the launch
-                stream inside the timed steps, HBM traffic from the committed PMC summary;
+                stream inside the timed steps, HBM traffic from the committed PMC summary of this
+                same command (null when no committed pass holds this kernel instantiation);
   cpu_baseline  the CPU oracle (a PyTorch-CPU port of the reference) timed on this box's host
                 cores on a bounded sample (N=1 only), and the PSNR criterion of BASELINE.json on
-                the weights that were timed.
+                the weights that were timed;
+  aux           (render mode, N=1) a few seconds each of the other BASELINE.json configurations,
+                measured AFTER the timed region of the headline: the same render with bf16 operands
+                (the type north_star names; its PSNR delta is reported beside the fp16 default's),
+                config 2 (400x400x64, exact-fp32 MFMA), config 4 (800x800 hierarchical 64+128 in one
+                library call) and config 5 (the training step as replayed hipGraphs, N = 64 and 128);
+  N > 1         per-rank kernel ms, the collective's ms (events around it on the launch stream), and
+                self-checks that fail loudly: backend is nccl (= RCCL), one distinct device per rank,
+                the rank-sum all-reduce.
 """
 import argparse
 import json
@@ -47,7 +56,10 @@ H = W = 800
 N_SAMPLES = 128
 TRAIN_RAYS, TRAIN_SAMPLES = 4096, 64   # per GPU (reference configs/lego.yaml:12; BASELINE config 5)
 DW_BYTES_PER_POINT = 11_776            # operands nerf_amd_param_gradients reads once per point
-PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in ("r02_bench_pmc.json", "r02e_train_pmc.json")]
+# committed rocprofv3 PMC summaries (tools/profile_gpu.sh + tools/summarize_prof.py), newest first
+PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in
+                 ("r03_bench_fp16_pmc.json", "r03_bench_bf16_pmc.json", "r03_train_pmc.json",
+                  "r02_bench_pmc.json", "r02e_train_pmc.json")]
 
 
 def parse():
@@ -59,6 +71,7 @@ def parse():
     ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
                     help="MFMA operand type of the render (train mode is bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary configurations (render mode, N=1)")
     ap.add_argument("--cpu-rays", type=int, default=16000,
                     help="rays of the CPU-baseline sample (x128 samples; the reference's test batch)")
     a = ap.parse_args()
@@ -79,6 +92,10 @@ def spawn_ranks(n):
     s.close()
     procs = []
     for r in range(n):
+        # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool supports dmabuf IPC only; with the legacy mode
+        # RCCL's (and torch's) cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.
+        # The image exports it already; it is repeated here so a rank started from a scrubbed environment still
+        # gets it, and an explicit setting of the caller wins.  
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
@@ -153,17 +170,27 @@ def cpu_baseline(sd, rays_cpu, n_rays):
             "seconds": dt}, (rays, u, out, O)
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of a kernel from the committed PMC summaries (separate rocprofv3 --pmc passes of
-    this same command, tools/profile_gpu.sh): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 wide-read correction,
-    MI355X_MICROARCH.md section HBM), both in KB.  None if no summary holds that kernel."""
+def pmc_traffic(kernel, mode, precision=None):
+    """HBM bytes per launch of ``kernel`` -- the FULL template instantiation, e.g.
+    'nerf_mlp_f16_16_kernel<true, false, true>' -- from a committed PMC summary of THIS command (separate rocprofv3
+    --pmc passes, tools/profile_gpu.sh): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 wide-read correction,
+    MI355X_MICROARCH.md section HBM), both in KB.  A summary counts only if it was taken from the same mode (and,
+    for renders, the same --precision; summaries record their bench arguments) and holds exactly that instantiation;
+    otherwise (None, None): the number is a stored constant of a profiled run, never of another workload."""
     for path in PMC_SUMMARIES:
         try:
             summary = json.load(open(path))
         except (OSError, ValueError):
             continue
+        cmd = summary.get("bench_args")
+        if cmd is not None:
+            words = cmd.split()
+            got_mode = words[words.index("--mode") + 1] if "--mode" in words else "render"
+            got_prec = words[words.index("--precision") + 1] if "--precision" in words else "fp16"
+            if got_mode != mode or (mode == "render" and precision is not None and got_prec != precision):
+                continue
         for name, c in summary.get("kernels", {}).items():
-            if kernel_substr in name and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            if name.startswith(kernel) and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
                 return (c["WRITE_SIZE"] + 2.0 * c["FETCH_SIZE"]) * 1024.0, os.path.relpath(path, ROOT)
     return None, None
 
@@ -218,18 +245,159 @@ def timed_loop(step, args, dist, dev, world):
 
 
 def ranks_seen(dist, dev, world):
-    """What the collective backend itself reports: sum of (rank + 1) over the group and its size."""
+    """What the collective backend itself reports -- and the self-checks of a multi-GPU run, which raise instead
+    of letting a mis-launched job print a number: the backend is nccl (= RCCL on ROCm) unless the rehearsal knob
+    NERF_BENCH_BACKEND says otherwise, every rank sits on its own device unless NERF_BENCH_SHARE_GPU=1, and an
+    all-reduce of (rank + 1) over the group gives world (world + 1) / 2."""
     if world == 1:
         return {"world_size": 1, "rank_sum_check": True}
     t = torch.tensor([float(dist.get_rank() + 1)], device=dev)
     dist.all_reduce(t)
-    return {"world_size": dist.get_world_size(), "rank_sum_check": float(t.item()) == world * (world + 1) / 2,
-            "backend": dist.get_backend()}
+    props = torch.cuda.get_device_properties(dev)
+    ident = (socket.gethostname(), str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", dev.index)), dev.index)
+    idents = [None] * world
+    dist.all_gather_object(idents, ident)
+    distinct = len({(h, u) for h, u, _ in idents}) == world
+    seen = {"world_size": dist.get_world_size(), "rank_sum_check": float(t.item()) == world * (world + 1) / 2,
+            "backend": dist.get_backend(), "devices_distinct": distinct, "device_index_per_rank": [i for _, _, i in idents]}
+    if not seen["rank_sum_check"] or seen["world_size"] != world:
+        raise SystemExit(f"collective self-check failed: {seen}")
+    if "NERF_BENCH_BACKEND" not in os.environ and seen["backend"] != "nccl":
+        raise SystemExit(f"multi-GPU runs use RCCL (backend 'nccl'), got {seen['backend']!r}")
+    if os.environ.get("NERF_BENCH_SHARE_GPU") != "1" and not distinct:
+        raise SystemExit(f"ranks share a device: {idents}")
+    return seen
+
+
+def gather_floats(dist, dev, world, value):
+    """One float per rank -> list on every rank."""
+    if world == 1:
+        return [float(value)]
+    t = torch.zeros(world, dtype=torch.float64, device=dev)
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t)
+    return [float(x) for x in t.tolist()]
 
 
 # ----------------------------------------------------------------------------------------------
 # render mode (BASELINE config 3)
 # ----------------------------------------------------------------------------------------------
+RENDER_KERNEL = {"bf16": "nerf_mlp_bf16_16_kernel<true, false, true>", "fp16": "nerf_mlp_f16_16_kernel<true, false, true>",
+                 "fp32": "nerf_mlp_f32_kernel<true, true>"}
+
+
+def event_timed(fn, steps, warmup, dev):
+    """Average duration of fn() in ms from HIP events on the launch stream (all steps in one bracket)."""
+    for _ in range(warmup):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) / steps
+
+
+def aux_configs(dev, sd, rays_800):
+    """The other BASELINE.json configurations, a few seconds each on this one GPU, through the C ABI / the same host
+    objects the tests use.  Returns the ``aux`` object of the JSON line (PSNR of the bf16 render is added by the
+    cpu_baseline leg, which owns the CPU renders)."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.optim import FusedAdam
+    from nerf_simple_amd.training import GraphedTrainStep
+    from nerf_simple_amd.utils import synthetic
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    import numpy as np
+    lib = _lib.lib()
+    st = lambda: _lib.stream_ptr(dev)                                    # noqa: E731
+    aux = {}
+
+    def net_of(precision, seed=0, kind="structured"):
+        n = Nerf(precision=precision).to(dev)
+        n.load_state_dict(synthetic.synthetic_state_dict(seed, kind))
+        return n
+
+    # ---- config 3 with bf16 operands: the same launch, the other 16-bit type
+    n_rays = rays_800.shape[0]
+    packed = net_of("bf16").packed_weights(_lib.BF16)
+    tb = torch.linspace(2, 6, N_SAMPLES + 1).to(dev)
+    px = torch.empty((n_rays, 4), dtype=torch.float32, device=dev)
+    ms = event_timed(lambda: _lib.check(lib.nerf_amd_render_pixels_forward(
+        _lib.ptr(rays_800), None, _lib.ptr(tb), _lib.ptr(packed), _lib.BF16, _lib.FLAG_DEVICE_RNG, 1234, 0, _lib.ptr(px), None,
+        n_rays, N_SAMPLES, st()), "render bf16"), 20, 3, dev)
+    samples = n_rays * N_SAMPLES
+    tf_ = samples * FLOP_PER_SAMPLE / (ms * 1e-3)
+    traffic, src = pmc_traffic(RENDER_KERNEL["bf16"], "render", "bf16")
+    aux["bf16"] = {"workload": "config 3 (800x800x128) with bf16 MFMA operands, the type BASELINE config 3 names", "ms": ms,
+                   "ray_samples_per_s": samples / (ms * 1e-3), "kernel": RENDER_KERNEL["bf16"], "tflops": tf_ / 1e12,
+                   "frac_of_peak": tf_ / PEAK_BF16, "peak_tflops": PEAK_BF16 / 1e12, "steps": 20, "traffic": traffic,
+                   "traffic_source": src}
+
+    # ---- config 2: 400x400, 64 samples per ray, exact-fp32 MFMA
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
+    r2 = camera_rays([pose], [400, 400, synthetic.focal_from_fov(400)]).to(dev).contiguous()
+    packed = net_of("fp32").packed_weights(_lib.F32)
+    tb = torch.linspace(2, 6, 65).to(dev)
+    px2 = torch.empty((r2.shape[0], 4), dtype=torch.float32, device=dev)
+    ms = event_timed(lambda: _lib.check(lib.nerf_amd_render_pixels_forward(
+        _lib.ptr(r2), None, _lib.ptr(tb), _lib.ptr(packed), _lib.F32, _lib.FLAG_DEVICE_RNG, 1234, 0, _lib.ptr(px2), None,
+        r2.shape[0], 64, st()), "render fp32"), 12, 2, dev)
+    samples = r2.shape[0] * 64
+    tf_ = samples * FLOP_PER_SAMPLE / (ms * 1e-3)
+    aux["c2"] = {"workload": "config 2: 400x400 render, 64 samples/ray, fp32 (exact-f32 MFMA), one launch", "ms": ms,
+                 "ray_samples_per_s": samples / (ms * 1e-3), "kernel": RENDER_KERNEL["fp32"], "tflops": tf_ / 1e12,
+                 "frac_of_peak": tf_ / PEAK_F32, "peak_tflops": PEAK_F32 / 1e12, "steps": 12}
+
+    # ---- config 4: 800x800 hierarchical, 64 coarse + 128 fine (192 positions in the fine pass), ONE library call
+    nc, nf = net_of("fp16", 0), net_of("fp16", 7)
+    pc, pf = nc.packed_weights(_lib.FP16), nf.packed_weights(_lib.FP16)
+    h_pose = np.zeros((3, 4), dtype=np.float32)
+    h_pose[:] = spherical_to_pose(4, -30, 0)[:3, :4]
+    f = float(synthetic.focal_from_fov(W))
+    ws = torch.empty(int(lib.nerf_amd_render_hierarchical_workspace_bytes(n_rays, 64, 128)), dtype=torch.uint8, device=dev)
+    tbc = torch.linspace(2, 6, 65).to(dev)
+    ms = event_timed(lambda: _lib.check(lib.nerf_amd_render_hierarchical_forward(
+        h_pose.ctypes.data, H, W, f, 0, n_rays, None, None, _lib.ptr(tbc), _lib.ptr(pc), _lib.ptr(pf), _lib.FP16,
+        _lib.FLAG_DEVICE_RNG, 3, _lib.ptr(px), _lib.ptr(ws), 64, 128, st()), "hierarchical"), 8, 2, dev)
+    evals = n_rays * (64 + 192)
+    tf_ = evals * FLOP_PER_SAMPLE / (ms * 1e-3)
+    aux["c4"] = {"workload": "config 4: 800x800 hierarchical 64 coarse + 128 fine in ONE library call (ray generation, coarse "
+                             "fused render, sample_pdf, fine fused render on 192 merged positions), fp16 operands, 1 GPU; "
+                             "parity unpinned (the reference has no hierarchical sampling)", "ms": ms,
+                 "mlp_evaluations_per_s": evals / (ms * 1e-3), "kernel": RENDER_KERNEL["fp16"] + " x2 + sample_pdf_kernel + generate_rays_kernel",
+                 "tflops": tf_ / 1e12, "frac_of_peak": tf_ / PEAK_BF16, "peak_tflops": PEAK_BF16 / 1e12, "steps": 8}
+    del ws, px, px2
+
+    # ---- config 5: the training step (train.py:47-57), replayed hipGraphs, at the sample count BASELINE names (64)
+    #      and at the reference's own (Nf = 128, configs/lego.yaml:6)
+    aux["c5"] = {}
+    pose5 = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
+    rays5 = camera_rays([pose5], [64, 64, synthetic.focal_from_fov(64)]).to(dev).contiguous()
+    gen = torch.Generator().manual_seed(100)
+    gt5 = torch.rand(TRAIN_RAYS, 3, generator=gen).to(dev)
+    for N, steps in ((64, 600), (128, 300)):
+        net = net_of("bf16", 0, "default")
+        stepper = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), TRAIN_RAYS, N)
+        us = [torch.rand(TRAIN_RAYS, N, generator=gen).to(dev) for _ in range(2)]
+        k = [0]
+
+        def one():
+            stepper.step(rays5, gt5, u=us[k[0] & 1])
+            k[0] += 1
+
+        ms = event_timed(one, steps, 30, dev)
+        P = TRAIN_RAYS * N
+        aux["c5"][f"N{N}"] = {"workload": f"config 5: train.py step, 4096 rays x {N} samples, bf16, FusedAdam, hipGraph replay, 1 GPU",
+                              "ms": ms, "ray_samples_per_s": P / (ms * 1e-3),
+                              "kernel": "nerf_mlp_bf16_16_kernel<true, true, false> + composite_backward_kernel + nerf_mlp_bwd_kernel + dw_gemm_kernel + adam_hyper_kernel + pack_train_kernel",
+                              "step_mfma_frac": 3 * FLOP_PER_SAMPLE * P / (ms * 1e-3) / PEAK_BF16, "peak_tflops": PEAK_BF16 / 1e12,
+                              "final_loss": float(stepper.loss), "steps": steps}
+        del stepper, net
+    return aux
+
+
 def run_render(args):
     world, rank, dev, dist, backend = init_rank(args)
     from nerf_simple_amd import _lib, parallel
@@ -252,7 +420,7 @@ def run_render(args):
     code = _lib.precision_code(args.precision)
     packed = net.packed_weights(code)
     tbins = torch.linspace(2, 6, N_SAMPLES + 1).to(dev)
-    nws = int(lib.nerf_amd_render_workspace_bytes(code, nr, N_SAMPLES))       # 0 for the fused 16-bit render
+    nws = int(lib.nerf_amd_render_workspace_bytes(code, nr, N_SAMPLES))       # 0 for the fused render
     ws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws else None
     shard = torch.empty((nr, 4), dtype=torch.float32, device=dev)
     image = torch.empty((n_rays, 4), dtype=torch.float32, device=dev) if world > 1 else shard
@@ -261,29 +429,38 @@ def run_render(args):
     def step(record):
         st = _lib.stream_ptr(dev)
         if record:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 if world > 1 else 2)]
+            ev[0].record()
         _lib.check(lib.nerf_amd_render_pixels_forward(
             _lib.ptr(rays), None, _lib.ptr(tbins), _lib.ptr(packed), code, _lib.FLAG_DEVICE_RNG, 1234, lo,
             _lib.ptr(shard), _lib.ptr(ws), nr, N_SAMPLES, st), "nerf_amd_render_pixels_forward")
         if record:
-            e1.record()
-            events.append((e0, e1))
+            ev[1].record()
         if world > 1:
             parallel.gather_pixels(shard, n_rays, out=image)     # ONE RCCL all-gather per image
+            if record:
+                ev[2].record()
+        if record:
+            events.append(ev)
 
     elapsed = timed_loop(step, args, dist, dev, world)
     seen = ranks_seen(dist, dev, world)
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(len(events), 1)
+    kern_ms = sum(e[0].elapsed_time(e[1]) for e in events) / max(len(events), 1)
+    coll_ms = sum(e[1].elapsed_time(e[2]) for e in events) / max(len(events), 1) if world > 1 else 0.0
+    kern_ms_ranks = gather_floats(dist, dev, world, kern_ms)
+    coll_ms_ranks = gather_floats(dist, dev, world, coll_ms)
+    from nerf_simple_amd.utils.nets import packed_status
+    range_flags = packed_status(packed, code)
+    if range_flags:
+        raise SystemExit(f"the timed render left the operand range (status word {range_flags}): the number would be of NaN pixels")
     if rank == 0:
         total_samples = n_rays * N_SAMPLES * args.steps
         value = total_samples / elapsed
         peak = PEAK_F32 if args.precision == "fp32" else PEAK_BF16      # fp16 and bf16 MFMA rates are equal
         launch_samples = nr * N_SAMPLES
         achieved = launch_samples * FLOP_PER_SAMPLE / (kern_ms * 1e-3) / 1e12
-        kern = {"bf16": "nerf_mlp_bf16_16_kernel<true, false, true>", "fp16": "nerf_mlp_f16_16_kernel<true, false, true>",
-                "fp32": "nerf_mlp_f32_kernel<true>"}[args.precision]
-        traffic, traffic_src = pmc_traffic(kern.split("<")[0]) if world == 1 else (None, None)
+        kern = RENDER_KERNEL[args.precision]
+        traffic, traffic_src = pmc_traffic(kern, "render", args.precision) if world == 1 else (None, None)
         res = {
             "metric": "ray-samples/sec at 800x800x128", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -295,16 +472,27 @@ def run_render(args):
                        "launches_per_step": 1 if nws == 0 else 2,
                        "jitter": "device counter RNG", "weights": "synthetic_state_dict(0,'structured')",
                        "operands": {"fp16": "fp16 MFMA operands, fp32 accumulate (same dense peak as bf16; the 16-bit type that "
-                                            "meets the 0.05 dB PSNR target on these weights: DESIGN.md section 2)",
+                                            "meets the 0.05 dB PSNR target on these weights: DESIGN.md section 2; bf16 is timed "
+                                            "in aux.bf16 and misses that target: known gap)",
                                     "bf16": "bf16 MFMA operands, fp32 accumulate", "fp32": "exact-f32 MFMA"}[args.precision],
                        "parallelism": f"rays sharded x{world}" + (" + all_gather of [rgb,disp]" if world > 1 else "")},
             "ranks": seen,
+            "kernel_ms_per_rank": kern_ms_ranks,
+            "collective_ms": max(coll_ms_ranks) if world > 1 else 0.0,
+            "collective_ms_per_rank": coll_ms_ranks if world > 1 else [],
+            "collective": "all_gather_into_tensor of the packed [rgb, disparity] pixels, events on the launch stream "
+                          "from the end of the render kernel to the end of the gather" if world > 1 else None,
             "roofline": {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak / 1e12,
                          "unit": "TFLOP/s", "frac": achieved * 1e12 / peak, "traffic": traffic,
-                         "traffic_source": traffic_src, "algorithmic_hbm_bytes": nr * 40,
+                         "traffic_source": traffic_src,
+                         "traffic_kind": "HBM bytes per launch from the committed rocprofv3 PMC passes of this command "
+                                         "(WRITE_SIZE + 2 x FETCH_SIZE); not re-measured in this run",
+                         "algorithmic_hbm_bytes": nr * 40,
                          "kernel_ms": kern_ms, "flop_per_sample": FLOP_PER_SAMPLE,
                          "samples_per_launch": launch_samples},
         }
+        if world == 1 and not args.no_aux:
+            res["aux"] = aux_configs(dev, sd, rays)
         if world == 1 and not args.no_cpu_baseline:
             base, (crays, cu, cout, O) = cpu_baseline(sd, rays_cpu, args.cpu_rays)
             with torch.no_grad():
@@ -320,6 +508,16 @@ def run_render(args):
             base["max_abs_rgb_err"] = float((g[0].cpu() - cout[0]).abs().max())
             base["gpu_over_cpu"] = value / base["value"]
             res["cpu_baseline"] = base
+            if "aux" in res and args.precision != "bf16":
+                with torch.no_grad():
+                    gb = render_nerf(crays.to(dev), net, N_SAMPLES, u=cu.to(dev), precision="bf16")
+                bf_rgb = torch.clip(gb[0].cpu(), 0, 1)
+                d = float(O.img_psnr(T, bf_rgb)) - base["psnr_cpu_vs_teacher_db"]
+                res["aux"]["bf16"].update({"psnr_gpu_vs_cpu_db": float(O.img_psnr(cpu_rgb, bf_rgb)), "psnr_delta_vs_teacher_db": d,
+                                           "meets_0.05_db": abs(d) <= 0.05,
+                                           "note": "bf16's 8-bit weight mantissa shifts the image systematically on these "
+                                                   "high-gain weights (DESIGN.md section 2): the 0.05 dB criterion is a known "
+                                                   "gap of the bf16 operand mode, which is why fp16 operands are the default"})
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -343,7 +541,7 @@ def run_train(args):
     net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
     parallel.broadcast_parameters(net)
     opt = FusedAdam(net, lr=5e-4)
-    stepper = GraphedTrainStep(net, opt, B, N, group=(dist.group.WORLD if world > 1 else None))
+    stepper = GraphedTrainStep(net, opt, B, N, group=(dist.group.WORLD if world > 1 else None), timing=world > 1)
     # synthetic batch: 4096 rays of a 64x64 camera on this rank's own azimuth, random targets, four
     # pre-drawn jitter tables cycled through (the reference's per-step host work is out of the timed path)
     pose = torch.from_numpy(spherical_to_pose(4, -30, 20.0 * rank)).float()
@@ -359,6 +557,7 @@ def run_train(args):
         it[0] += 1
 
     elapsed = timed_loop(step, args, dist, dev, world)
+    coll = stepper.collective_times() if world > 1 else None      # (span, exposed) ms per step, warm-up included
     seen = ranks_seen(dist, dev, world)
     loss = float(stepper.loss)
     # duration of the dominant kernel (dW + db, nerf_amd_param_gradients): 20 more launches on the same
@@ -376,11 +575,14 @@ def run_train(args):
         evs.append((e0, e1))
     torch.cuda.synchronize(dev)
     dw_ms = sorted(a.elapsed_time(b) for a, b in evs)[len(evs) // 2]
+    dw_ms_ranks = gather_floats(dist, dev, world, dw_ms)
+    span_ranks = gather_floats(dist, dev, world, coll[0] if coll else 0.0)
+    exposed_ranks = gather_floats(dist, dev, world, coll[1] if coll else 0.0)
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * P * args.steps / elapsed
         achieved = DW_BYTES_PER_POINT * P / (dw_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic("dw_gemm_kernel") if world == 1 else (None, None)
+        traffic, traffic_src = pmc_traffic("dw_gemm_kernel(", "train") if world == 1 else (None, None)
         res = {
             "metric": "training ray-samples/sec (forward + backward + Adam) at 4096 rays x 64 samples per GPU",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -391,6 +593,13 @@ def run_train(args):
                        "rays_per_gpu": B, "samples_per_ray": N, "global_batch_rays": B * world,
                        "parallelism": f"data-parallel x{world}" + (" + all_reduce of the flat 2.38 MB gradient" if world > 1 else "")},
             "ranks": seen, "final_loss": loss,
+            "kernel_ms_per_rank": dw_ms_ranks,
+            "collective_ms": max(span_ranks) if world > 1 else 0.0,
+            "collective_exposed_ms": max(exposed_ranks) if world > 1 else 0.0,
+            "collective_ms_per_rank": span_ranks if world > 1 else [],
+            "collective": "two all-reduces of the flat gradient (1.27 MB, then 1.12 MB); collective_ms = from the end of the "
+                          "late-layer gradient launch to both reduced, collective_exposed_ms = the part behind the end of the "
+                          "head-gradient launch that runs beside the first exchange" if world > 1 else None,
             "roofline": {"bound": "hbm", "kernel": "dw_gemm_kernel (timed: nerf_amd_param_gradients = zero fill + d_raw pack + dw_gemm)",
                          "achieved": achieved, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / PEAK_HBM,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": dw_ms,

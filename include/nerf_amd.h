@@ -10,7 +10,9 @@
  *
  * Conventions (all entry points):
  *   - every pointer is a DEVICE pointer unless its name starts with `h_`;
- *     fp32, row-major, contiguous; never written unless documented as output;
+ *     fp32, row-major, contiguous; never written unless documented as output
+ *     (one exception, which is why `packed` is not const where a 16-bit MLP kernel may run: the
+ *     sticky status word behind a packed 16-bit image, see nerf_amd_packed_status_offset);
  *   - the library allocates nothing, frees nothing and keeps no pointer after
  *     return; workspaces are caller-provided;
  *   - `stream` is a hipStream_t passed as void*; calls are asynchronous on it,
@@ -28,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 2
+#define NERF_AMD_ABI_VERSION 3
 
 /* error codes */
 #define NERF_AMD_EINVAL   (-1)   /* bad argument (null pointer, negative size, ...) */
@@ -50,6 +52,18 @@ int      nerf_amd_abi_version(void);
 int64_t  nerf_amd_param_count(void);
 /* bytes of the packed weight image for a precision (the caller allocates it) */
 int64_t  nerf_amd_packed_bytes(int precision);
+/* Range guard of the 16-bit images.  The reference is fp32 with no range limit (utils/nets.py:16-32); fp16
+ * operands overflow beyond 65504.  A packed NERF_AMD_FP16 / NERF_AMD_BF16 image ends with a 256-byte status
+ * block of sticky uint32 flags (0 / 1), zeroed by nerf_amd_pack_weights:
+ *   word NERF_AMD_STATUS_WORD_NONFINITE     set by every 16-bit MLP forward kernel when a point's (rgb, sigma) output
+ *                                           is inf or NaN (where an overflowed hidden activation ends up);
+ *   word NERF_AMD_STATUS_WORD_WEIGHT_RANGE  set by the packer if a finite weight is not finite in the operand type.
+ * Returns the byte offset of word 0 inside the image, -1 for images without a status block (NERF_AMD_F32,
+ * NERF_AMD_BF16_BWD).  The host wrapper (utils/nets.py) reads it after the first fp16 render of a weight set and
+ * falls back to bf16 operands with a warning instead of returning NaN pixels. */
+#define NERF_AMD_STATUS_WORD_NONFINITE     0
+#define NERF_AMD_STATUS_WORD_WEIGHT_RANGE  1
+int64_t  nerf_amd_packed_status_offset(int precision);
 /* bytes of workspace nerf_amd_render_forward / _pixels_forward need for B rays x N samples.
  * 0 up to 768 samples per ray: those renders run as ONE launch (sampling + encoding + MLP +
  * compositing, samples composited out of LDS) and `workspace` may be NULL; longer rays take the
@@ -85,13 +99,25 @@ int nerf_amd_positional_encoder(const float* vec, float* posx, float* posd,
 /* pts[P,6] = [x,y,z,d1,d2,d3] -> out[P,4] = [r,g,b,sigma] (raw: no sigmoid, no
  * softplus).  Encoding + 12 dense layers fused in one kernel; activations never
  * leave the CU.  `packed` from nerf_amd_pack_weights with the same precision. */
-int nerf_amd_mlp_forward(const float* pts, const void* packed, float* out,
+int nerf_amd_mlp_forward(const float* pts, void* packed, float* out,
                          int64_t P, int precision, void* stream);
+
+/* ---- sampling + query points on their own: utils/rendering.py:24-40 ------------ */
+/* rays[B,6] (+ u / ts / device RNG and tbins as in nerf_amd_render_forward) -> query_pts[B*N,6] =
+ * [origin + direction * t, direction / ||direction||] ray-major / sample-minor, and ts[B,N] (may be NULL).
+ * For a caller whose network is not the fused one (render_nerf with a foreign `net`): that net's own forward
+ * runs on query_pts, nerf_amd_volume_render_rays composites. */
+int nerf_amd_query_points(const float* rays, const float* u, const float* tbins,
+                          uint32_t flags, uint64_t seed, int64_t ray_id0,
+                          float* query_pts, float* ts, int64_t B, int N, void* stream);
 
 /* ---- compositing: volume_render, utils/rendering.py:47-85 -------------------- */
 /* raw[B,N,4], ts[B,N], dirs[B] (3 floats at stride `dirs_stride` floats) ->
  * rgb[B,3], disp[B], alpha[B,N], acc[B], w[B,N].  alpha and w may be NULL.
- * One wavefront per ray; transmittance by a wave-level product scan. */
+ * One wavefront per ray; transmittance by a wave-level product scan.
+ * N == 1 reproduces the reference's degenerate result (every compositing entry point and the fused renders):
+ * its delta construction (utils/rendering.py:60-61) leaves the sample axis EMPTY there, so rgb = acc = 0,
+ * disparity = NaN, alpha / w (shape [B,0] in the reference) are not written and d_raw is zero. */
 int nerf_amd_volume_render(const float* raw, const float* ts,
                            const float* dirs, int64_t dirs_stride,
                            float* rgb, float* disp, float* alpha, float* acc, float* w,
@@ -144,7 +170,7 @@ int nerf_amd_volume_render_mse_backward(const float* raw, const float* ts, const
  *   alpha,w  optional (NULL to skip the 8 B/sample of output traffic)
  *   workspace  nerf_amd_render_workspace_bytes(precision,B,N) bytes, 256-B aligned (NULL if 0) */
 int nerf_amd_render_forward(const float* rays, const float* u, const float* tbins,
-                            const void* packed, int precision, uint32_t flags,
+                            void* packed, int precision, uint32_t flags,
                             uint64_t seed, int64_t ray_id0,
                             float* rgb, float* disp, float* alpha, float* acc, float* w,
                             void* workspace, int64_t B, int N, void* stream);
@@ -152,7 +178,7 @@ int nerf_amd_render_forward(const float* rays, const float* u, const float* tbin
 /* Image-driver form (the body of utils/rendering.py:102-105 for one batch): the same render, output
  * pixels[B,4] = [clip(rgb,0,1), disparity]; rgb is clipped AFTER compositing, disparity is not. */
 int nerf_amd_render_pixels_forward(const float* rays, const float* u, const float* tbins,
-                                   const void* packed, int precision, uint32_t flags,
+                                   void* packed, int precision, uint32_t flags,
                                    uint64_t seed, int64_t ray_id0,
                                    float* pixels, void* workspace, int64_t B, int N, void* stream);
 
@@ -160,7 +186,7 @@ int nerf_amd_render_pixels_forward(const float* rays, const float* u, const floa
  * raw[B,N,4] and ts[B,N].  Exposed for the importance-sampling caller, which
  * needs explicit ts. */
 int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tbins,
-                              const void* packed, int precision, uint32_t flags,
+                              void* packed, int precision, uint32_t flags,
                               uint64_t seed, int64_t ray_id0,
                               float* raw, float* ts, int64_t B, int N, void* stream);
 
@@ -180,7 +206,7 @@ int64_t nerf_amd_render_image_workspace_bytes(int precision, int64_t n_rays, int
 int nerf_amd_render_image_forward(const float* h_pose, int H, int W, float f,
                                   int64_t ray0, int64_t n_rays,
                                   const float* u, const float* tbins,
-                                  const void* packed, int precision, uint32_t flags, uint64_t seed,
+                                  void* packed, int precision, uint32_t flags, uint64_t seed,
                                   float* pixels, void* workspace, int N, void* stream);
 
 /* ---- hierarchical sampling (BASELINE config 4) -------------------------------- */
@@ -206,7 +232,7 @@ int64_t nerf_amd_render_hierarchical_workspace_bytes(int64_t n_rays, int Nc, int
 int nerf_amd_render_hierarchical_forward(const float* h_pose, int H, int W, float f,
                                          int64_t ray0, int64_t n_rays,
                                          const float* u_c, const float* u_f, const float* tbins_c,
-                                         const void* packed_c, const void* packed_f, int precision,
+                                         void* packed_c, void* packed_f, int precision,
                                          uint32_t flags, uint64_t seed,
                                          float* pixels, void* workspace, int Nc, int Nf, void* stream);
 
@@ -231,11 +257,11 @@ int nerf_amd_sample_encode(const float* rays, const float* u, const float* tbins
  * decoded in tests/test_gpu_training.py.) */
 int64_t nerf_amd_train_activation_bytes(int64_t P);
 int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* tbins,
-                               const void* packed_bf16, uint32_t flags, uint64_t seed, int64_t ray_id0,
+                               void* packed_bf16, uint32_t flags, uint64_t seed, int64_t ray_id0,
                                float* raw, float* ts, void* acts, int64_t B, int N, void* stream);
 /* The same for explicit points, i.e. Nerf.forward(v) under autograd (utils/nets.py:34-43):
  * pts[P,6] -> out[P,4], activations saved as above; and the matching bf16 encoder rows. */
-int nerf_amd_mlp_forward_train_points(const float* pts, const void* packed_bf16, float* out,
+int nerf_amd_mlp_forward_train_points(const float* pts, void* packed_bf16, float* out,
                                       void* acts, int64_t P, void* stream);
 int nerf_amd_encode_points_bf16(const float* pts, void* posx64, void* posd32, int64_t P, void* stream);
 /* Backward dX chain: d_raw[P,4] (from nerf_amd_volume_render_backward) + the ReLU
@@ -267,6 +293,13 @@ int nerf_amd_param_gradients(const float* d_raw, const void* acts, const void* d
 int nerf_amd_param_gradients_begin(const float* d_raw, void* scratch, float* grads, int64_t P, void* stream);
 int nerf_amd_param_gradients_finish(const void* acts, const void* dys, const void* posx64, const void* posd32,
                                     const void* scratch, float* grads, int64_t P, void* stream);
+/* Data-parallel training reduces `grads` in two buckets so the exchange overlaps the arithmetic: bucket 1 =
+ * skip_conn_layer ... color_fc.2 (the tail of the vector, whose products run first), bucket 2 = layers_0.* (its
+ * head); bucket 0 = everything (= nerf_amd_param_gradients_finish).  nerf_amd_grad_bucket_range gives a bucket's
+ * [first, first + count) inside the flat vector.  The caller all-reduces bucket 1 while bucket 2 is computed. */
+int nerf_amd_grad_bucket_range(int bucket, int64_t* h_first, int64_t* h_count);
+int nerf_amd_param_gradients_finish_bucket(const void* acts, const void* dys, const void* posx64, const void* posd32,
+                                           const void* scratch, float* grads, int64_t P, int bucket, void* stream);
 
 /* ---- loss: nn.MSELoss(), reference train.py:42,52 -------------------------------- */
 /* loss[0] = mean((pred - target)^2) over n elements; g_pred[n] (may be NULL) =

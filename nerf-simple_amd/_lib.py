@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
 
 F32, BF16, FP16, BF16_BWD = 0, 1, 2, 3
 FLAG_TS_GIVEN, FLAG_DEVICE_RNG = 1, 2
+STATUS_NONFINITE, STATUS_WEIGHT_RANGE = 1, 2
 _PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, F32: F32,
                "bf16": BF16, "bfloat16": BF16, BF16: BF16,
                "fp16": FP16, "f16": FP16, "float16": FP16, "half": FP16, FP16: FP16,
@@ -36,6 +37,10 @@ _SIGNATURES = {
     "nerf_amd_param_count": (_i64, []),
     "nerf_amd_packed_bytes": (_i64, [_i32]),
     "nerf_amd_render_workspace_bytes": (_i64, [_i32, _i64, _i32]),
+    "nerf_amd_packed_status_offset": (_i64, [_i32]),
+    "nerf_amd_query_points": (_i32, [_vp, _vp, _vp, _u32, _u64, _i64, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_grad_bucket_range": (_i32, [_i32, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "nerf_amd_param_gradients_finish_bucket": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_layout_selfcheck": (_i32, []),
     "nerf_amd_layout_src_col": (_i32, [_i32, _i32, _i32, _i32, _i32]),
     "nerf_amd_pack_weights": (_i32, [_vp, _vp, _i32, _vp]),
@@ -106,7 +111,7 @@ def lib():
                 for name, (res, args) in _SIGNATURES.items():
                     fn = getattr(h, name)          # AttributeError if an export is missing
                     fn.restype, fn.argtypes = res, args
-                if h.nerf_amd_abi_version() != 2:
+                if h.nerf_amd_abi_version() != 3:
                     raise RuntimeError("libnerf_amd.so ABI version mismatch")
                 _lib = h
     return _lib

@@ -14,7 +14,8 @@ int nerf_amd_launch_composite_mse_backward(const float*, const float*, const flo
                                            int, hipStream_t);
 int nerf_amd_launch_param_gradients_begin(const float*, void*, float*, long long, hipStream_t);
 int nerf_amd_launch_param_gradients_finish(const void*, const void*, const void*, const void*, const void*, float*, long long,
-                                           hipStream_t);
+                                           int, hipStream_t);
+int nerf_amd_launch_query_points(const MlpArgs*, float*, hipStream_t);
 int nerf_amd_launch_gamma(const float*, long long, float*, long long, int, hipStream_t);
 int nerf_amd_launch_posenc(const float*, float*, float*, long long, int, int, hipStream_t);
 int nerf_amd_launch_composite(const float*, const float*, const float*, long long, float*, float*,
@@ -67,6 +68,18 @@ int64_t nerf_amd_packed_bytes(int precision) {
     if (bad_image(precision)) return NERF_AMD_EINVAL;
     if (precision == NERF_AMD_BF16_BWD) return BWD_IMAGE_BYTES;
     return precision == NERF_AMD_F32 ? F32_PACKED_BYTES : B16_IMAGE_BYTES;
+}
+
+int64_t nerf_amd_packed_status_offset(int precision) {
+    if (bad_image(precision)) return NERF_AMD_EINVAL;
+    return (precision == NERF_AMD_BF16 || precision == NERF_AMD_FP16) ? B16_STATUS_OFF : -1;
+}
+
+int nerf_amd_grad_bucket_range(int bucket, int64_t* first, int64_t* count) {
+    if (!first || !count || bucket < 0 || bucket > 2) return NERF_AMD_EINVAL;
+    *first = bucket == 1 ? GRAD_BUCKET_SPLIT : 0;
+    *count = bucket == 0 ? PARAM_COUNT : bucket == 1 ? PARAM_COUNT - GRAD_BUCKET_SPLIT : GRAD_BUCKET_SPLIT;
+    return 0;
 }
 
 int64_t nerf_amd_render_image_workspace_bytes(int precision, int64_t n_rays, int N) {
@@ -156,7 +169,20 @@ int nerf_amd_positional_encoder(const float* vec, float* posx, float* posd, int6
     return nerf_amd_launch_posenc(vec, posx, posd, P, Lp, Ld, S(stream));
 }
 
-int nerf_amd_mlp_forward(const float* pts, const void* packed, float* out, int64_t P, int precision,
+int nerf_amd_query_points(const float* rays, const float* u, const float* tbins, uint32_t flags, uint64_t seed,
+                          int64_t ray_id0, float* query_pts, float* ts, int64_t B, int N, void* stream) {
+    if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    if (!rays || !query_pts) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
+    if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+    MlpArgs a{};
+    a.rays = rays; a.u = u; a.tbins = tbins; a.ts_out = ts;
+    a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
+    return nerf_amd_launch_query_points(&a, query_pts, S(stream));
+}
+
+int nerf_amd_mlp_forward(const float* pts, void* packed, float* out, int64_t P, int precision,
                          void* stream) {
     if (P < 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
     if (P == 0) return 0;
@@ -243,7 +269,7 @@ int nerf_amd_sample_encode(const float* rays, const float* u, const float* tbins
     return nerf_amd_launch_sample_encode(&a, posx, posd, S(stream));
 }
 
-int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tbins, const void* packed,
+int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tbins, void* packed,
                               int precision, uint32_t flags, uint64_t seed, int64_t ray_id0, float* raw,
                               float* ts, int64_t B, int N, void* stream) {
     if (B < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
@@ -257,7 +283,7 @@ int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tb
     return launch_mlp(a, 1, precision, S(stream));
 }
 
-int nerf_amd_render_forward(const float* rays, const float* u, const float* tbins, const void* packed,
+int nerf_amd_render_forward(const float* rays, const float* u, const float* tbins, void* packed,
                             int precision, uint32_t flags, uint64_t seed, int64_t ray_id0, float* rgb,
                             float* disp, float* alpha, float* acc, float* w, void* workspace, int64_t B,
                             int N, void* stream) {
@@ -284,7 +310,7 @@ int nerf_amd_render_forward(const float* rays, const float* u, const float* tbin
     return nerf_amd_launch_composite(raw, ts, rays + 3, 6, rgb, disp, alpha, acc, w, B, N, 1, nullptr, S(stream));
 }
 
-int nerf_amd_render_pixels_forward(const float* rays, const float* u, const float* tbins, const void* packed,
+int nerf_amd_render_pixels_forward(const float* rays, const float* u, const float* tbins, void* packed,
                                    int precision, uint32_t flags, uint64_t seed, int64_t ray_id0, float* pixels,
                                    void* workspace, int64_t B, int N, void* stream) {
     if (B < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
@@ -320,7 +346,7 @@ int nerf_amd_generate_rays(const float* h_pose, int H, int W, float f, int64_t r
 }
 
 int nerf_amd_render_image_forward(const float* h_pose, int H, int W, float f, int64_t ray0, int64_t n_rays,
-                                  const float* u, const float* tbins, const void* packed, int precision,
+                                  const float* u, const float* tbins, void* packed, int precision,
                                   uint32_t flags, uint64_t seed, float* pixels, void* workspace, int N,
                                   void* stream) {
     if (n_rays < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
@@ -354,7 +380,7 @@ int64_t nerf_amd_render_hierarchical_workspace_bytes(int64_t n_rays, int Nc, int
 
 int nerf_amd_render_hierarchical_forward(const float* h_pose, int H, int W, float f, int64_t ray0, int64_t n_rays,
                                          const float* u_c, const float* u_f, const float* tbins_c,
-                                         const void* packed_c, const void* packed_f, int precision, uint32_t flags,
+                                         void* packed_c, void* packed_f, int precision, uint32_t flags,
                                          uint64_t seed, float* pixels, void* workspace, int Nc, int Nf, void* stream) {
     if (n_rays < 0 || Nc <= 0 || Nf < 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
     if (n_rays == 0) return 0;
@@ -390,7 +416,7 @@ int64_t nerf_amd_train_activation_bytes(int64_t P) {
     return P < 0 ? (int64_t)NERF_AMD_EINVAL : (int64_t)acts_total_bytes(P);
 }
 
-int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* tbins, const void* packed,
+int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* tbins, void* packed,
                                uint32_t flags, uint64_t seed, int64_t ray_id0, float* raw, float* ts,
                                void* acts, int64_t B, int N, void* stream) {
     if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
@@ -404,7 +430,7 @@ int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* t
     return nerf_amd_launch_mlp_bf16_16(&a, 1, S(stream));
 }
 
-int nerf_amd_mlp_forward_train_points(const float* pts, const void* packed, float* out, void* acts, int64_t P,
+int nerf_amd_mlp_forward_train_points(const float* pts, void* packed, float* out, void* acts, int64_t P,
                                       void* stream) {
     if (P < 0) return NERF_AMD_EINVAL;
     if (P == 0) return 0;
@@ -462,9 +488,14 @@ int nerf_amd_param_gradients_begin(const float* d_raw, void* scratch, float* gra
 
 int nerf_amd_param_gradients_finish(const void* acts, const void* dys, const void* posx64, const void* posd32,
                                     const void* scratch, float* grads, int64_t P, void* stream) {
-    if (P < 0 || !grads) return NERF_AMD_EINVAL;
+    return nerf_amd_param_gradients_finish_bucket(acts, dys, posx64, posd32, scratch, grads, P, 0, stream);
+}
+
+int nerf_amd_param_gradients_finish_bucket(const void* acts, const void* dys, const void* posx64, const void* posd32,
+                                           const void* scratch, float* grads, int64_t P, int bucket, void* stream) {
+    if (P < 0 || !grads || bucket < 0 || bucket > 2) return NERF_AMD_EINVAL;
     if (P > 0 && (!acts || !dys || !posx64 || !posd32 || !scratch)) return NERF_AMD_EINVAL;
-    return nerf_amd_launch_param_gradients_finish(acts, dys, posx64, posd32, scratch, grads, P, S(stream));
+    return nerf_amd_launch_param_gradients_finish(acts, dys, posx64, posd32, scratch, grads, P, bucket, S(stream));
 }
 
 int nerf_amd_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

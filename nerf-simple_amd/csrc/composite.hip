@@ -85,6 +85,14 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_backward_kernel
     const float* rts = ts + ray * N;
     const f32x4* rraw = reinterpret_cast<const f32x4*>(raw) + ray * N;
     f32x4* rout = reinterpret_cast<f32x4*>(d_raw) + ray * N;
+    if (N == 1) {
+        // the reference composites an EMPTY sample axis at N == 1 (composite_device.h): no output depends on raw
+        if (lane == 0) {
+            rout[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (mse_target && rgb_out) { rgb_out[ray * 3 + 0] = 0.f; rgb_out[ray * 3 + 1] = 0.f; rgb_out[ray * 3 + 2] = 0.f; }
+        }
+        return;
+    }
 
     // forward sweep: per chunk keep alpha, T, fac, delta*softplus' and the colour
     float al[MAX_CHUNKS], Tt[MAX_CHUNKS], fc[MAX_CHUNKS], ds[MAX_CHUNKS], tt[MAX_CHUNKS];

@@ -68,6 +68,10 @@ __device__ __forceinline__ void composite_ray(const Src& src, int N, int lane, f
                                               const RayOut& o) {
     float carry = 1.0f;                        // transmittance entering this chunk
     float sr = 0.f, sg = 0.f, sb = 0.f, sd = 0.f, sa = 0.f;
+    // N == 1 in the reference: deltas = cat(ts[:,1:] - ts[:,:-1], 1e10 * ones_like(deltas[:, :1])) is built from an
+    // EMPTY [B,0] difference, so the sample axis stays empty (utils/rendering.py:60-61): alpha / w are [B,0],
+    // rgb = acc = 0 and disparity = 1 / max(1e-10, 0/0) = NaN.  Reproduced by compositing no sample at all.
+    if (N == 1) N = 0;
     for (int base = 0; base < N; base += 64) {
         const int i = base + lane;
         const bool valid = i < N;

@@ -344,9 +344,13 @@ extern "C" int nerf_amd_launch_param_gradients_begin(const float* d_raw, void* s
     return (int)hipGetLastError();
 }
 
+// bucket 0: all 14 products in one launch.  Buckets 1 and 2 split them at the boundary of the flat gradient
+// vector that data-parallel training reduces in two pieces (nerf_layout.h GRAD_BUCKET_SPLIT): bucket 1 = the LATE
+// layers (skip_conn_layer ... color_fc.2, the tail of the vector), bucket 2 = layers_0.* (its head), so the
+// all-reduce of bucket 1 runs while bucket 2 is still being computed.  Either launch fills the chip.
 extern "C" int nerf_amd_launch_param_gradients_finish(const void* acts_v, const void* dys_v, const void* posx64_v,
                                                       const void* posd32_v, const void* scratch, float* grads,
-                                                      long long P, hipStream_t stream) {
+                                                      long long P, int bucket, hipStream_t stream) {
     (void)hipGetLastError();
     hipError_t e = hipSuccess;
     if (P <= 0) return 0;
@@ -384,6 +388,15 @@ extern "C" int nerf_amd_launch_param_gradients_finish(const void* acts_v, const 
     add(dy(9), BLK, 128, act(8), BLK, 256, OFF_C0_W, 283, 0, 128, 256, OFF_C0_B);         // color_fc.0 [h ; d]: h part
     add(dy(9), BLK, 128, posd, 32, 32, OFF_C0_W + 256, 283, 0, 128, 27);                  //                      d part
     add(dsr, 32, 32, act(9), BLK, 128, OFF_C1_W, 128, 0, 3, 128);                         // color_fc.2 (rows 0..2)
+    if (bucket != 0) {
+        // keep the products whose destination lies in this bucket's part of the flat vector
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const bool head = t.d[i].C - grads < GRAD_BUCKET_SPLIT;
+            if (head == (bucket == 2)) t.d[m++] = t.d[i];
+        }
+        n = m;
+    }
     t.n = n;
     // workgroups per product, one per CU in total.  A slab costs a workgroup the bytes it streams,
     // (M + N) * 2 per point, plus a fixed part (barrier, DMA issue, fragment reads) that measures
@@ -391,8 +404,7 @@ extern "C" int nerf_amd_launch_param_gradients_finish(const void* acts_v, const 
     // 256 / 1024 / 8192 give 0.79 / 0.63 / 0.62 / 0.61 ms at 262144 points.  (Sizing by flops
     // left the thin products -- 32 x 256 reads as much of X as 256 x 256 -- as a 2 ms tail.)
     constexpr double slab_cost = 1024.0;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const int cus = device_cus();
     double total = 0;
     for (int i = 0; i < n; ++i) total += (double)(t.d[i].M + t.d[i].N) + slab_cost;
     const long long nslab = (P + SLAB - 1) / SLAB;
@@ -424,8 +436,7 @@ extern "C" int nerf_amd_launch_param_gradients_finish(const void* acts_v, const 
         t.d[i].wgs = (int)w[i];
         wg += (int)w[i];
     }
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(dw_gemm_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    e = allow_dynamic_lds(reinterpret_cast<const void*>(dw_gemm_kernel), LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dw_gemm_kernel, dim3(wg), dim3(512), LDS_BYTES, stream, t);
 
@@ -437,5 +448,5 @@ extern "C" int nerf_amd_launch_param_gradients(const float* d_raw, const void* a
                                                float* grads, long long P, hipStream_t stream) {
     const int rc = nerf_amd_launch_param_gradients_begin(d_raw, scratch, grads, P, stream);
     if (rc) return rc;
-    return nerf_amd_launch_param_gradients_finish(acts_v, dys_v, posx64_v, posd32_v, scratch, grads, P, stream);
+    return nerf_amd_launch_param_gradients_finish(acts_v, dys_v, posx64_v, posd32_v, scratch, grads, P, 0, stream);
 }

@@ -138,6 +138,17 @@ __global__ __launch_bounds__(256) void sample_encode_bf16_kernel(MlpArgs a, __bf
     }
 }
 
+// Sampling + query-point assembly on their own (reference utils/rendering.py:24-40), for callers whose network is
+// not the fused one: query_pts[P,6] = [o + d t, d / ||d||] ray-major / sample-minor, ts[B,N].  One thread per point.
+__global__ __launch_bounds__(256) void query_points_kernel(MlpArgs a, float* __restrict__ query_pts) {
+    const long long p = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (p >= a.P) return;
+    const PointIn pt = fetch_point_rays(a, p);
+    if (a.ts_out) a.ts_out[p] = pt.t;
+    float* q = query_pts + p * 6;
+    q[0] = pt.x; q[1] = pt.y; q[2] = pt.z; q[3] = pt.d1; q[4] = pt.d2; q[5] = pt.d3;
+}
+
 __host__ int grid_for(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 256 * 32 ? 256 * 32 : g));
@@ -166,6 +177,13 @@ extern "C" int nerf_amd_launch_sample_encode(const MlpArgs* args, float* posx, f
     (void)hipGetLastError();
     if (args->P == 0) return 0;
     hipLaunchKernelGGL(sample_encode_kernel, dim3(grid_for(args->P * 90)), dim3(256), 0, stream, *args, posx, posd);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nerf_amd_launch_query_points(const MlpArgs* args, float* query_pts, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (args->P == 0) return 0;
+    hipLaunchKernelGGL(query_points_kernel, dim3((unsigned)((args->P + 255) / 256)), dim3(256), 0, stream, *args, query_pts);
     return (int)hipGetLastError();
 }
 

@@ -124,6 +124,7 @@ struct State {
     ex8 X[NCB][8], Y[NCB][8];        // [column block][k-step of 32]
     f32x4 pend[NCB][2];               // [column block][tile of the pending pair]
     float sigma[NCB], rgb[NCB][3];
+    bool bad;                         // range guard: a non-finite accumulator was seen (flag_nonfinite)
     // training forward only (SAVE): where this lane's activations go
     char* acts;
     long long P;
@@ -183,6 +184,13 @@ template <int L, int Q, bool SAVE = false>
 __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2], ex8 (&dst)[NCB][8], State& st) {
     constexpr LayerDesc D = layer_desc(L);
     const int cb = i >> 2, j2 = i & 3;   // i in [0, 4*NCB)
+    if constexpr (Q == 0 && L >= 1 && L <= 9) {
+        // Range guard.  If ANY input feature of this layer is inf (an fp16 activation beyond 65504) every one of its
+        // rows sums w * inf: +-inf, or NaN with two of them -- so one accumulator element per point tells.  (The
+        // outputs alone do not: the integer ReLU below turns a NaN with the sign bit set into 0, and a layer whose
+        // rows are all NaN comes out as all zeros, finite from there on.)  One compare per column block and layer.
+        if (j2 == 0) st.bad |= __builtin_amdgcn_classf(acc[cb][0][0], 0x207);      // sNaN | qNaN | -inf | +inf
+    }
     if constexpr (L == 10) {
         if (j2 == 0) { st.rgb[cb][0] = acc[cb][0][0]; st.rgb[cb][1] = acc[cb][0][1]; st.rgb[cb][2] = acc[cb][0][2]; }
     } else if constexpr (L == 8 && Q == 8) {
@@ -548,6 +556,20 @@ __device__ __forceinline__ void run_tile(const Ctx& c, const MlpArgs& a, long lo
     for (int cb_ = 1; cb_ < NCB; ++cb_) epilogue_piece<10, 0>(4 * cb_, st.pend, st.X, st);
 }
 
+// Sticky range flag (nerf_layout.h B16_STATUS_OFF): a point with a non-finite accumulator in layers 1..9 (epilogue_piece)
+// or a non-finite (rgb, sigma) sets status word 0 behind the packed image.  The host wrapper reads it
+// (utils/nets.py): the reference is fp32 and has no range limit (utils/nets.py:16-32), so an overflowing fp16 render
+// must not pass silently.  A plain store of the constant 1 through the weight image's own buffer descriptor (every
+// writer writes the same value: no atomic, no extra pointer kept live across the tile loop).
+__device__ __forceinline__ void flag_nonfinite(const Ctx& c, bool bad) {
+    if (bad) __builtin_amdgcn_raw_buffer_store_b32(1u, c.wrsrc, (int)(B16_STATUS_OFF + 4 * NERF_STATUS_WORD_NONFINITE), 0, 0);
+}
+__device__ __forceinline__ bool finite4(float x, float y, float z, float w) {
+    // |v| < inf is false for inf and NaN; the sum is non-finite iff any term is (no finite sum of four floats overflows
+    // unless a term is already beyond half of FLT_MAX -- which fp16 / bf16 MLP outputs of a usable network never are)
+    return __builtin_fabsf(x) + __builtin_fabsf(y) + __builtin_fabsf(z) + __builtin_fabsf(w) < __builtin_inff();
+}
+
 struct RingSamples {                         // a ray's samples in the workgroup's LDS ring
     unsigned q0;                              // ring slot of its sample 0
     __device__ __forceinline__ float t(int i) const {
@@ -605,7 +627,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
             st.P = a.P;
             st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
             st.tile = tile;
+            st.bad = false;
             run_tile<RAYS, SAVE, false>(c, a, tile_base, st);
+            bool bad = st.bad;
             if (c.lane < 16) {
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
@@ -613,9 +637,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
                     if (p < a.P) {
                         const f32x4 o = {st.rgb[cb][0], st.rgb[cb][1], st.rgb[cb][2], st.sigma[cb]};
                         *reinterpret_cast<f32x4*>(a.raw + p * 4) = o;
+                        bad |= !finite4(o[0], o[1], o[2], o[3]);
                     }
                 }
             }
+            flag_nonfinite(c, bad);
         }
     } else {
         // ---- fused render: this workgroup's contiguous range of rays, tile after tile ----------
@@ -636,7 +662,9 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
             st.tile = 0;
             st.p_end = range_base + n_pts;
             st.ring_q0 = (unsigned)q_tile & (RING_PTS - 1);
+            st.bad = false;
             run_tile<true, false, true>(c, a, tile_base, st);
+            bool bad = st.bad;
             if (c.lane < 16) {
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) {
@@ -644,9 +672,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
                     if (q_tile + local < n_pts) {
                         const f32x4 o = {st.rgb[cb][0], st.rgb[cb][1], st.rgb[cb][2], st.sigma[cb]};
                         lds_store<f32x4>(((st.ring_q0 + local) & (RING_PTS - 1)) * 16, LDS_RING_RAW, o);
+                        bad |= !finite4(o[0], o[1], o[2], o[3]);
                     }
                 }
             }
+            flag_nonfinite(c, bad);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                             // every wave's samples of this tile are in the ring
             asm volatile("" ::: "memory");
@@ -677,20 +707,16 @@ extern "C" int NERF_LAUNCH(const MlpArgs* args, int rays_mode, hipStream_t strea
     MlpArgs a = *args;
     if (a.P <= 0) return 0;
     const long long ntiles = (a.P + TILE_PTS - 1) / TILE_PTS;
-    int dev = 0, cus = 256;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return (int)e;
+    const int cus = device_cus();
     const long long grid = ntiles < cus ? ntiles : cus;
+    hipError_t e = hipSuccess;
     const bool comp = a.rgb || a.disp || a.acc || a.alpha || a.w || a.pixels;
     if (comp) {
         // fused render: rays mode, inference; a ray plus one tile must fit the LDS ring, and a
         // workgroup's share of the points must fit an int
         if (!rays_mode || a.acts || a.N > COMP_MAX_N || a.P / grid + a.N >= (1ll << 31)) return -2;
         auto kern = NERF_KERNEL<true, false, true>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_TOTAL_COMP);
+        e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_TOTAL_COMP);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), LDS_TOTAL_COMP, stream, a, ntiles);
         return (int)hipGetLastError();
@@ -703,8 +729,7 @@ extern "C" int NERF_LAUNCH(const MlpArgs* args, int rays_mode, hipStream_t strea
     auto kern = a.acts ? NERF_KERNEL<true, true, false>
                        : (rays_mode ? NERF_KERNEL<true, false, false> : NERF_KERNEL<false, false, false>);
 #endif
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_TOTAL);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), LDS_TOTAL, stream, a, ntiles);
     return (int)hipGetLastError();

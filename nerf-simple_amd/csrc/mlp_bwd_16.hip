@@ -326,14 +326,9 @@ extern "C" int nerf_amd_launch_mlp_backward(const float* d_raw, const void* imag
     if (P <= 0) return 0;
     BwdArgs a{d_raw, image, reinterpret_cast<const char*>(acts), reinterpret_cast<char*>(dys), P};
     const long long ntiles = (P + TILE_PTS - 1) / TILE_PTS;
-    int dev = 0, cus = 256;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return (int)e;
+    const int cus = device_cus();
     const long long grid = ntiles < cus ? ntiles : cus;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_mlp_bwd_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    const hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(nerf_mlp_bwd_kernel), LDS_TOTAL);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(nerf_mlp_bwd_kernel, dim3((unsigned)grid), dim3(WAVES * 64), LDS_TOTAL, stream, a, ntiles);
     return (int)hipGetLastError();

@@ -361,18 +361,14 @@ extern "C" int nerf_amd_launch_mlp_f32(const MlpArgs* args, int rays_mode, hipSt
     MlpArgs a = *args;
     if (a.P <= 0) return 0;
     const long long ntiles = (a.P + TILE_PTS - 1) / TILE_PTS;
-    int dev = 0, cus = 256;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (e != hipSuccess) return (int)e;
+    const int cus = device_cus();
     const long long grid = ntiles < cus ? ntiles : cus;
     const bool comp = a.rgb || a.disp || a.acc || a.alpha || a.w || a.pixels;
     if (comp && (!rays_mode || a.N > FUSED_RENDER_MAX_N || a.P / grid + a.N >= (1ll << 31))) return -2;
     auto kern = comp ? nerf_mlp_f32_kernel<true, true>
                      : (rays_mode ? nerf_mlp_f32_kernel<true, false> : nerf_mlp_f32_kernel<false, false>);
     const int lds = comp ? LDS_TOTAL_COMP : LDS_TOTAL;
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), lds, stream, a, ntiles);
     return (int)hipGetLastError();

@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "nerf_layout.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -42,6 +43,42 @@ struct MlpArgs {
     float* w;             // [B,N]
     float* pixels;        // [B,4] = [clip(rgb,0,1), disparity]
 };
+
+// ---- host: per-device launch facts, looked up once ----------------------------------
+// Every launcher used to call hipGetDevice + hipDeviceGetAttribute + hipFuncSetAttribute per launch: a few
+// microseconds each on the eager small-batch path.  Both answers are constants of (device) and (kernel, device).
+constexpr int NERF_MAX_DEVICES = 64;
+inline int device_cus() {
+    static int cache[NERF_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NERF_MAX_DEVICES) return 256;
+    if (cache[dev] == 0) {
+        int cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        cache[dev] = cus;                      // racing threads store the same value
+    }
+    return cache[dev];
+}
+// hipFuncAttributeMaxDynamicSharedMemorySize for `kernel` on the current device, set once per (kernel, device).
+inline hipError_t allow_dynamic_lds(const void* kernel, int bytes) {
+    struct Slot { const void* kernel; int dev; };
+    static Slot slots[128];
+    static std::atomic<int> used{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    const int n = used.load(std::memory_order_acquire);
+    for (int i = 0; i < n && i < 128; ++i)
+        if (slots[i].kernel == kernel && slots[i].dev == dev) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && dev >= 0) {
+        const int i = used.load(std::memory_order_relaxed);
+        if (i < 128) {                          // a racing thread may overwrite the slot: the loser just sets the attribute again later
+            slots[i] = Slot{kernel, dev};
+            used.store(i + 1, std::memory_order_release);
+        }
+    }
+    return e;
+}
 
 // ---- chunk barrier of the MLP kernels --------------------------------------------
 // Loads, LDS-DMA and stores share vmcnt on gfx9-family parts and retire in issue order, so

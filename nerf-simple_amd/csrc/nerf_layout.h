@@ -48,6 +48,10 @@ constexpr int OFF_C0_B = OFF_C0_W + 128 * 283;
 constexpr int OFF_C1_W = OFF_C0_B + 128;            // 3x128
 constexpr int OFF_C1_B = OFF_C1_W + 3 * 128;
 static_assert(OFF_C1_B + 3 == PARAM_COUNT, "parameter offsets");
+// Data-parallel training reduces the flat gradient vector in two pieces: [0, SPLIT) = layers_0.* and
+// [SPLIT, PARAM_COUNT) = skip_conn_layer ... color_fc.2; the second piece is computed first (dw_gemm.hip).
+constexpr int GRAD_BUCKET_SPLIT = OFF_SKIP_W;          // 279,552 floats (1.12 MB) | 316,292 floats (1.27 MB)
+static_assert(GRAD_BUCKET_SPLIT % 4 == 0, "16-byte aligned buckets");
 
 struct LayerDesc {
     int w_off, b_off;     // into the flat parameter vector
@@ -161,8 +165,15 @@ NL_HD constexpr int b16_bias_off(int L) {
     return o;
 }
 constexpr int B16_BIAS_FLOATS = b16_bias_off(NUM_LAYERS);            // 2464
-// the packed 16-bit buffer (bf16 or fp16): [weight image | bias table (fp32, natural row order)]
-constexpr long long B16_IMAGE_BYTES = (long long)B16_WEIGHT_KIB * 1024 + B16_BIAS_FLOATS * 4;
+// the packed 16-bit buffer (bf16 or fp16): [weight image | bias table (fp32, natural row order) | status block]
+// Status block: 256 bytes of sticky uint32 flags (0 / 1), zeroed by the packer.  Word 0 is set by the MLP kernels when
+// a point's output is not finite, word 1 by the packer when a weight does not fit the operand type (|w| > 65504 in
+// fp16).  One word per writer: each flag is a plain store of 1.
+constexpr long long B16_STATUS_OFF = (long long)B16_WEIGHT_KIB * 1024 + B16_BIAS_FLOATS * 4;
+constexpr int B16_STATUS_BYTES = 256;
+constexpr int NERF_STATUS_WORD_NONFINITE = 0, NERF_STATUS_WORD_WEIGHT_RANGE = 1;
+constexpr long long B16_IMAGE_BYTES = B16_STATUS_OFF + B16_STATUS_BYTES;
+static_assert(B16_STATUS_OFF % 16 == 0, "aligned status block");
 
 // ---- backward (dX chain) image, bf16, 16-row tiles -------------------------------
 // Training backward of the dense layers: dX = W^T dY.  The same on-chip chaining

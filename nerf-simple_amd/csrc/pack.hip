@@ -9,7 +9,7 @@ namespace {
 
 // 16-bit image (bf16 or fp16), 16-row tiles: [tile (layer, rt)][k-step][lane][8 elements]
 template <class T>
-__global__ void pack_b16_kernel(const float* __restrict__ params, T* __restrict__ out) {
+__global__ void pack_b16_kernel(const float* __restrict__ params, T* __restrict__ out, unsigned* __restrict__ status) {
     const long long total = (long long)B16_WEIGHT_KIB * 512;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
          e += (long long)gridDim.x * blockDim.x) {
@@ -20,7 +20,13 @@ __global__ void pack_b16_kernel(const float* __restrict__ params, T* __restrict_
         const int rt = rel / b16_ks(L), s = rel % b16_ks(L);
         const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
         const int row = 16 * rt + (lane & 15), g = lane >> 4;
-        out[e] = (T)weight_at(params, L, row, src_col_b16(L, s, g, j));
+        const float wv = weight_at(params, L, row, src_col_b16(L, s, g, j));
+        const T cv = (T)wv;
+        out[e] = cv;
+        // a finite weight that is not finite in the operand type (fp16: |w| > 65504): sticky flag (the status word
+        // was zeroed by pack_bias_kernel, launched in front of this kernel)
+        if (__builtin_fabsf(wv) < __builtin_inff() && !(__builtin_fabsf((float)cv) < __builtin_inff()))
+            status[NERF_STATUS_WORD_WEIGHT_RANGE] = 1u;
     }
 }
 
@@ -64,8 +70,10 @@ __global__ void pack_f32_kernel(const float* __restrict__ params, float* __restr
 }
 
 // bias table: natural row order, 16 rows per tile (the 16-bit and the f32 kernels share it)
-__global__ void pack_bias_kernel(const float* __restrict__ params, float* __restrict__ out) {
+// status != NULL (16-bit images): also zero the status block behind the bias table
+__global__ void pack_bias_kernel(const float* __restrict__ params, float* __restrict__ out, unsigned* __restrict__ status) {
     static_assert(B16_BIAS_FLOATS == F32_BIAS_FLOATS, "one bias table layout");
+    if (status && blockIdx.x == 0 && threadIdx.x < B16_STATUS_BYTES / 4) status[threadIdx.x] = 0u;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < F32_BIAS_FLOATS; e += gridDim.x * blockDim.x) {
         int L = 0;
         while (L + 1 < NUM_LAYERS && e >= f32_bias_off(L + 1)) ++L;
@@ -75,7 +83,8 @@ __global__ void pack_bias_kernel(const float* __restrict__ params, float* __rest
 
 // the three images of a training step in ONE launch: forward bf16 image, its bias table, backward image
 __global__ void pack_train_kernel(const float* __restrict__ params, __bf16* __restrict__ img, float* __restrict__ bias,
-                                  __bf16* __restrict__ bwd) {
+                                  __bf16* __restrict__ bwd, unsigned* __restrict__ status) {
+    if (blockIdx.x == 0 && threadIdx.x < B16_STATUS_BYTES / 4) status[threadIdx.x] = 0u;
     const long long n_img = (long long)B16_WEIGHT_KIB * 512, n_bwd = (long long)BWD_WEIGHT_KIB * 512;
     const long long total = n_img + n_bwd + F32_BIAS_FLOATS;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
@@ -113,7 +122,8 @@ extern "C" int nerf_amd_launch_pack_train(const float* params, void* packed_bf16
     (void)hipGetLastError();
     char* img = reinterpret_cast<char*>(packed_bf16);
     hipLaunchKernelGGL(pack_train_kernel, dim3(2048), dim3(256), 0, stream, params, reinterpret_cast<__bf16*>(img),
-                       reinterpret_cast<float*>(img + (long long)B16_WEIGHT_KIB * 1024), reinterpret_cast<__bf16*>(packed_bwd));
+                       reinterpret_cast<float*>(img + (long long)B16_WEIGHT_KIB * 1024), reinterpret_cast<__bf16*>(packed_bwd),
+                       reinterpret_cast<unsigned*>(img + B16_STATUS_OFF));
     return (int)hipGetLastError();
 }
 
@@ -121,14 +131,15 @@ extern "C" int nerf_amd_launch_pack(const float* params, void* packed, int preci
     (void)hipGetLastError();   // drop any stale error: the return value is about THIS launch
     char* img = reinterpret_cast<char*>(packed);
     if (precision == 1 || precision == 2) {
+        unsigned* status = reinterpret_cast<unsigned*>(img + B16_STATUS_OFF);
+        hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params,
+                           reinterpret_cast<float*>(img + (long long)B16_WEIGHT_KIB * 1024), status);
         if (precision == 1)
             hipLaunchKernelGGL(pack_b16_kernel<__bf16>, dim3(1024), dim3(256), 0, stream, params,
-                               reinterpret_cast<__bf16*>(img));
+                               reinterpret_cast<__bf16*>(img), status);
         else
             hipLaunchKernelGGL(pack_b16_kernel<_Float16>, dim3(1024), dim3(256), 0, stream, params,
-                               reinterpret_cast<_Float16*>(img));
-        hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params,
-                           reinterpret_cast<float*>(img + (long long)B16_WEIGHT_KIB * 1024));
+                               reinterpret_cast<_Float16*>(img), status);
     } else if (precision == 3) {
         // training backward image (bf16)
         hipLaunchKernelGGL(pack_bwd_kernel, dim3(1024), dim3(256), 0, stream, params,
@@ -137,7 +148,7 @@ extern "C" int nerf_amd_launch_pack(const float* params, void* packed, int preci
         hipLaunchKernelGGL(pack_f32_kernel, dim3(1024), dim3(256), 0, stream, params,
                            reinterpret_cast<float*>(img));
         hipLaunchKernelGGL(pack_bias_kernel, dim3(10), dim3(256), 0, stream, params,
-                           reinterpret_cast<float*>(img + (long long)F32_WEIGHT_KIB * 1024));
+                           reinterpret_cast<float*>(img + (long long)F32_WEIGHT_KIB * 1024), static_cast<unsigned*>(nullptr));
     }
     return (int)hipGetLastError();
 }

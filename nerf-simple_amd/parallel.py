@@ -103,6 +103,28 @@ def allreduce_flat_(flat, group=None):
     return flat
 
 
+def allreduce_start_(t, group=None):
+    """Start the in-place mean of ``t`` over the data-parallel replicas without blocking the current stream: the
+    collective waits for what is queued on the current stream NOW and runs on the backend's own stream, so kernels
+    launched afterwards overlap it.  Returns a handle for allreduce_wait_ (None with a single replica)."""
+    rank, world = world_info(group)
+    if world == 1:
+        return None
+    avg = dist.get_backend(group) == "nccl"                 # RCCL reduces to the mean itself; gloo has no AVG
+    work = dist.all_reduce(t, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True)
+    return work, t, (None if avg else world)
+
+
+def allreduce_wait_(handle):
+    """Make the current stream wait for a collective started by allreduce_start_ (and finish the mean)."""
+    if handle is None:
+        return
+    work, t, div = handle
+    work.wait()
+    if div:
+        t /= div
+
+
 def allreduce_gradients(params, group=None):
     """Average gradients over data-parallel replicas with ONE collective: the
     grads are flattened into a single contiguous bucket (2.38 MB for the NeRF

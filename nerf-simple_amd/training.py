@@ -7,7 +7,7 @@ behind the C ABI, torch supplies tensors, streams, autograd bookkeeping and the 
                                                     kernel, also saving point-blocked bf16 activations
                                                     and ReLU mask bit planes)
   sigma -> alpha compositing, forward               nerf_amd_volume_render
-  MSE loss and its gradient                         nerf_amd_mse_loss (GraphedTrainStep) / torch (eager)
+  MSE loss and its gradient                         nerf_amd_mse_loss
   compositing, backward (suffix-sum scan)           nerf_amd_volume_render_backward
   dense layers, backward dX chain (on-chip)         nerf_amd_mlp_backward
   dense layers, dW = dY^T X and db = sum dY         nerf_amd_param_gradients (one split-K launch for
@@ -24,7 +24,6 @@ training path and no library-GEMM fallback (include/nerf_amd.h: NERF_AMD_EUNSUP)
 """
 
 import torch
-import torch.nn.functional as F
 
 from . import _lib
 
@@ -43,6 +42,40 @@ def img_psnr(gt, pred):
         gt = torch.from_numpy(gt).float()
     ten = torch.tensor(10.0)
     return 20 * torch.log(torch.max(gt)) / torch.log(ten) - 10 * torch.log(img_mse(gt, pred)) / torch.log(ten)
+
+
+# --------------------------------------------------------------------------
+# MSELoss with the HIP kernel (value and gradient in one launch)
+# --------------------------------------------------------------------------
+class _MseLoss(torch.autograd.Function):
+    """nn.MSELoss()(pred, target) (reference train.py:42,52: mean over all elements) through
+    nerf_amd_mse_loss: one launch writes the loss and 2 (pred - target) / n."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred, target = pred.contiguous(), target.contiguous()
+        if pred.shape != target.shape:
+            raise RuntimeError(f"mse_loss: shapes {tuple(pred.shape)} and {tuple(target.shape)} differ")
+        dev = pred.device
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        g_pred = torch.empty_like(pred)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().nerf_amd_mse_loss(_lib.ptr(pred), _lib.ptr(target), _lib.ptr(loss), _lib.ptr(g_pred),
+                                                    pred.numel(), _lib.stream_ptr(dev)), "nerf_amd_mse_loss")
+        ctx.save_for_backward(g_pred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (g_pred,) = ctx.saved_tensors
+        return g_pred * g, None
+
+
+def mse_loss(pred, target):
+    """criterion(rgb, gt_colors) of reference train.py:42,52 on device tensors (fp32)."""
+    _lib.require_cuda_f32(pred, "pred")
+    _lib.require_cuda_f32(target, "target")
+    return _MseLoss.apply(pred, target.detach())
 
 
 # --------------------------------------------------------------------------
@@ -76,6 +109,8 @@ class _VolumeRender(torch.autograd.Function):
                     "nerf_amd_volume_render")
         ctx.save_for_backward(raw, ts, dirs)
         ctx.from_rays = from_rays
+        if N == 1:        # the reference's empty sample axis (utils/rendering.py:60-61; csrc/composite_device.h)
+            alpha, w = alpha[:, :0], w[:, :0]
         return rgb, disp, alpha, acc, w
 
     @staticmethod
@@ -86,7 +121,7 @@ class _VolumeRender(torch.autograd.Function):
         d_raw = torch.empty_like(raw)
 
         def c(g):
-            return None if g is None else g.contiguous().float()
+            return None if (g is None or g.numel() == 0) else g.contiguous().float()
         g_rgb, g_disp, g_alpha, g_acc, g_w = map(c, (g_rgb, g_disp, g_alpha, g_acc, g_w))
         lib = _lib.lib()
         with torch.cuda.device(dev):
@@ -233,7 +268,7 @@ def train_step(net, optimizer, rays, gt, N, *, tn=2, tf=6, u=None, decay=1.0, gr
     optimizer.zero_grad(set_to_none=True)
     rgb, _, _, _, _ = render_nerf(rays, net, N, tn, tf, u=u, precision=precision,
                                   device_rng=device_rng, seed=seed, ray_id0=ray_id0)
-    loss = F.mse_loss(rgb, gt)
+    loss = mse_loss(rgb, gt)
     loss.backward()
     parallel.allreduce_gradients(net.parameters(), group=group)
     optimizer.step()
@@ -279,8 +314,18 @@ class GraphedTrainStep:
                  kernel) -> dX chain -> all 24 parameter gradients, with the encoder rows, the loss
                  value, the gradient zero fill and the d_raw pack on a parallel branch
                  (9 kernel nodes, all through the C ABI: no torch kernels, no memset node)
-        [one in-place all-reduce of the flat gradient vector when a process group is given]
         graph B: Adam over the flat parameter vector -> re-pack the two MFMA weight images (one kernel)
+
+    With a process group of more than one replica the parameter gradients are produced in two launches and the
+    flat vector is reduced in two buckets (include/nerf_amd.h nerf_amd_grad_bucket_range):
+
+        graph A1: ... -> dX chain -> gradients of the LATE layers (skip_conn_layer ... color_fc.2: the tail of the vector)
+        all-reduce of that bucket (1.27 MB) starts on the collective's own stream
+        graph A2: gradients of layers_0.* (the head of the vector)        <- runs while bucket 1 is on the wire
+        all-reduce of the head bucket (1.12 MB); both are awaited; graph B
+
+    so only the second, smaller exchange is exposed.  ``timing=True`` records events around the exchange
+    (``collective_times()``).
 
     Step-dependent scalars do not live in kernel arguments: the jitter comes from the ``u``
     buffer (filled per call; default the reference's one ``torch.rand(B, N)`` draw from the CPU
@@ -291,7 +336,8 @@ class GraphedTrainStep:
     ``step(rays, gt, u=None, decay=1.0)`` returns the loss as a 0-d device tensor (no sync).
     """
 
-    def __init__(self, net, optimizer, n_rays, N, *, tn=2, tf=6, group=None):
+    def __init__(self, net, optimizer, n_rays, N, *, tn=2, tf=6, group=None, timing=False):
+        from . import parallel
         from .optim import FusedAdam
         from .utils.rendering import _tbins
         if not isinstance(optimizer, FusedAdam):
@@ -300,6 +346,8 @@ class GraphedTrainStep:
             raise RuntimeError("the optimizer belongs to another module")
         _check_trainable(net.precision)
         self.net, self.opt, self.group = net, optimizer, group
+        self.bucketed = group is not None and parallel.world_info(group)[1] > 1
+        self.timing, self._events = bool(timing), []
         self.B, self.N = int(n_rays), int(N)
         dev = optimizer.flat.device
         self.dev = dev
@@ -323,6 +371,12 @@ class GraphedTrainStep:
         self.scratch = torch.empty(max(int(lib.nerf_amd_param_gradients_scratch_bytes(P)), 16), dtype=torch.uint8,
                                    device=dev)
         self.loss = torch.zeros((), **f32)
+        import ctypes
+        first, count = ctypes.c_int64(), ctypes.c_int64()
+        self.buckets = []                                   # views of the flat gradient vector, in exchange order
+        for b in (1, 2):
+            _lib.check(lib.nerf_amd_grad_bucket_range(b, ctypes.byref(first), ctypes.byref(count)), "nerf_amd_grad_bucket_range")
+            self.buckets.append(self.grads[first.value:first.value + count.value])
         self.hyper = torch.zeros(6, **f32)
         self._ring = _HyperRing()
         self._side = torch.cuda.Stream(dev)
@@ -335,8 +389,9 @@ class GraphedTrainStep:
         self._capture()
 
     # ---- the two launch sequences --------------------------------------------------
-    def _forward_backward(self):
-        """Main branch: forward -> compositing + MSE gradient + compositing backward -> dX chain -> dW.
+    def _forward_backward(self, bucket=0):
+        """Main branch: forward -> compositing + MSE gradient + compositing backward -> dX chain -> dW (all products,
+        or with ``bucket`` = 1 only those of the late layers: _late_gradients adds the rest).
         Side branch (a fork / join inside the captured graph): the encoder rows of the dW products
         beside the forward, then loss value + gradient-vector zero fill + d_raw pack beside the dX chain."""
         lib, B, N_, P = _lib.lib(), self.B, self.N, self.B * self.N
@@ -364,9 +419,16 @@ class GraphedTrainStep:
         ck(lib.nerf_amd_mlp_backward(ptr(self.d_raw), ptr(image), ptr(self.acts), ptr(self.dys), P, st),
            "nerf_amd_mlp_backward")
         main.wait_stream(side)
-        ck(lib.nerf_amd_param_gradients_finish(ptr(self.acts), ptr(self.dys), ptr(self.posx), ptr(self.posd),
-                                               ptr(self.scratch), ptr(self.grads), P, st),
-           "nerf_amd_param_gradients_finish")
+        ck(lib.nerf_amd_param_gradients_finish_bucket(ptr(self.acts), ptr(self.dys), ptr(self.posx), ptr(self.posd),
+                                                      ptr(self.scratch), ptr(self.grads), P, bucket, st),
+           "nerf_amd_param_gradients_finish_bucket")
+
+    def _head_gradients(self):
+        """The second launch of the bucketed form: the products of layers_0.* (bucket 2)."""
+        P = self.B * self.N
+        _lib.check(_lib.lib().nerf_amd_param_gradients_finish_bucket(
+            _lib.ptr(self.acts), _lib.ptr(self.dys), _lib.ptr(self.posx), _lib.ptr(self.posd), _lib.ptr(self.scratch),
+            _lib.ptr(self.grads), P, 2, _lib.stream_ptr(self.dev)), "nerf_amd_param_gradients_finish_bucket")
 
     def _update(self):
         lib, opt = _lib.lib(), self.opt
@@ -392,11 +454,17 @@ class GraphedTrainStep:
             side.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):                       # warm-up outside capture (lazy inits)
                 self._forward_backward()
+                self._head_gradients()
             torch.cuda.current_stream(self.dev).wait_stream(side)
             torch.cuda.synchronize(self.dev)
             self.graph_a = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_a):
-                self._forward_backward()
+                self._forward_backward(1 if self.bucketed else 0)
+            self.graph_a2 = None
+            if self.bucketed:
+                self.graph_a2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_a2):
+                    self._head_gradients()
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b):
                 self._update()
@@ -419,11 +487,39 @@ class GraphedTrainStep:
         self.opt.step_count += 1
         self._set_hyper(self.opt.step_count)
         self.graph_a.replay()
-        parallel.allreduce_flat_(self.grads, group=self.group)
+        if self.bucketed:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.timing else None
+            if ev:
+                ev[0].record()                                           # late gradients done, exchange starts
+            h1 = parallel.allreduce_start_(self.buckets[0], group=self.group)
+            self.graph_a2.replay()                                       # head gradients, beside the first exchange
+            if ev:
+                ev[1].record()
+            h2 = parallel.allreduce_start_(self.buckets[1], group=self.group)
+            parallel.allreduce_wait_(h1)
+            parallel.allreduce_wait_(h2)
+            if ev:
+                ev[2].record()
+                self._events.append(ev)
         self.graph_b.replay()
+        # graph B re-packed the two training images; any other image of the module (fp16 / fp32 inference) is now
+        # stale -- and the kernels wrote through the flat buffer, so the parameters' versions did not move
+        self.net.drop_packed(self.dev, keep=(_lib.BF16, _lib.BF16_BWD))
         if decay != 1.0:
             for pg in self.opt.param_groups:
                 pg["lr"] = pg["lr"] * decay
         return self.loss
 
     __call__ = step
+
+    def collective_times(self):
+        """(span_ms, exposed_ms) averaged over the steps recorded with timing=True: from the end of the late-layer
+        gradients to both buckets reduced, and the part of it behind the end of the head-gradient launch (what the
+        step actually waits for).  Synchronises; clears the record."""
+        if not self._events:
+            return None
+        torch.cuda.synchronize(self.dev)
+        span = sum(e[0].elapsed_time(e[2]) for e in self._events) / len(self._events)
+        exposed = sum(e[1].elapsed_time(e[2]) for e in self._events) / len(self._events)
+        self._events = []
+        return span, exposed

@@ -7,6 +7,8 @@ kernel (encoding + 12 dense layers in one launch, csrc/mlp_bf16_16.hip /
 csrc/mlp_f32.hip) on an MFMA-fragment-ordered copy of the weights.  That packed
 copy is a derived cache, rebuilt whenever a parameter changes.
 """
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -16,6 +18,91 @@ from .. import _lib
 # tried (bf16's 8-bit weight mantissa does not on high-gain weights: DESIGN.md section 2); 5 % slower
 # than bf16 (clock), values must stay below 65504.
 DEFAULT_PRECISION = "fp16"
+
+
+class _Packed:
+    """One packed weight image of a module: the device buffer, the parameter versions it was derived from,
+    and -- for the fp16 image -- the state of the range guard (guarded_launch)."""
+    __slots__ = ("stamp", "buf", "probed", "demoted", "host", "event")
+
+    def __init__(self, stamp, buf):
+        self.stamp, self.buf = stamp, buf
+        self.reset_guard()
+
+    def reset_guard(self):
+        self.probed = False          # the status word has been read once (blocking) after a launch with these weights
+        self.demoted = False         # these weights left the fp16 range: fp16 requests render with bf16 operands
+        self.host = None             # pinned int32[2]: lazily copied status words of later launches
+        self.event = None            # recorded behind that copy
+
+
+def _status_flags(words):
+    """The two status words of a packed 16-bit image (include/nerf_amd.h) as STATUS_* bits."""
+    return (_lib.STATUS_NONFINITE if int(words[0]) else 0) | (_lib.STATUS_WEIGHT_RANGE if int(words[1]) else 0)
+
+
+def packed_status(packed, code):
+    """STATUS_* bits of a packed image on the device (synchronises); 0 for images without a status block."""
+    off = int(_lib.lib().nerf_amd_packed_status_offset(code))
+    return 0 if off < 0 else _status_flags(packed[off:off + 8].view(torch.int32).cpu())
+
+
+def guarded_launch(nets, code, launch):
+    """Run ``launch(code, [packed image of each net])`` -- which enqueues kernels through the C ABI and returns
+    their outputs -- under the fp16 range guard.
+
+    The reference network is fp32 with no range limit (utils/nets.py:16-32); fp16 MFMA operands overflow beyond
+    65504 and an overflowed activation ends as inf / NaN pixels.  The 16-bit kernels therefore OR a sticky flag
+    into the status word behind the packed image whenever a point's (rgb, sigma) is not finite, and the packer
+    flags weights that do not fit (include/nerf_amd.h nerf_amd_packed_status_offset).  Policy, per weight set:
+      * the FIRST fp16 launch is followed by one blocking read of the word; if it is set, a UserWarning is
+        issued, the module is demoted to bf16 operands for these weights, and the call is repeated in bf16 --
+        the caller never sees the NaN pixels;
+      * later launches (other rays may still overflow) copy the word to pinned memory asynchronously and the
+        NEXT call looks at it without waiting: demotion then takes effect from that call on, with the warning
+        naming the earlier render.
+    Other precisions run unguarded (bf16 has fp32's exponent range)."""
+    if code != _lib.FP16:
+        return launch(code, [n.packed_weights(code) for n in nets])
+    ents = [n._packed_entry(_lib.FP16) for n in nets]
+
+    def in_bf16():
+        return launch(_lib.BF16, [n.packed_weights(_lib.BF16) for n in nets])
+
+    if any(e.demoted for e in ents):
+        return in_bf16()
+    dev = ents[0].buf.device
+    capturing = torch.cuda.is_current_stream_capturing()
+    off = int(_lib.lib().nerf_amd_packed_status_offset(_lib.FP16))
+    if not capturing:
+        late = 0
+        for n, e in zip(nets, ents):
+            if e.event is not None and e.event.query():
+                flags, e.event = _status_flags(e.host), None
+                if flags:
+                    n._demote(e, flags, "an earlier render")
+                    late |= flags
+        if late:
+            return in_bf16()
+    out = launch(_lib.FP16, [e.buf for e in ents])
+    if capturing:
+        return out
+    redo = False
+    for n, e in zip(nets, ents):
+        word = e.buf[off:off + 8].view(torch.int32)     # [non-finite output seen, weight out of range]
+        if not e.probed:
+            flags = _status_flags(word.cpu())           # blocking, once per weight set
+            e.probed = True
+            if flags:
+                n._demote(e, flags, "this render (repeated with bf16 operands)")
+                redo = True
+        elif e.event is None:
+            if e.host is None:
+                e.host = torch.zeros(2, dtype=torch.int32).pin_memory()
+            e.host.copy_(word, non_blocking=True)
+            e.event = torch.cuda.Event()
+            e.event.record(torch.cuda.current_stream(dev))
+    return in_bf16() if redo else out
 
 
 class Nerf(nn.Module):
@@ -35,6 +122,11 @@ class Nerf(nn.Module):
 
     def __init__(self, Lp=10, Ld=4, H=256, *, precision=None):
         super().__init__()
+        if (Lp, Ld, H) != (10, 4, 256):
+            # the kernels are built for the one shape the reference ever constructs (Nerf() at train.py:41, test.py:27):
+            # refuse at construction rather than hand out a module whose forward cannot run
+            raise RuntimeError(f"Nerf(Lp={Lp}, Ld={Ld}, H={H}): unsupported configuration (NERF_AMD_EUNSUP) -- the HIP "
+                               "kernels implement Lp=10, Ld=4, H=256 only; utils.xyz.positional_encoder / gamma take any L")
         self.Lp, self.Ld, self.H = Lp, Ld, H
         self.precision = precision or DEFAULT_PRECISION
         _lib.precision_code(self.precision)
@@ -53,7 +145,7 @@ class Nerf(nn.Module):
         self.sigma_fc = nn.Sequential(nn.Linear(H, 1))
         self.layers_2 = nn.Linear(H, H)
         self.color_fc = nn.Sequential(nn.Linear(H + cd, H // 2), nn.ReLU(), nn.Linear(H // 2, 3))
-        self._packed = {}       # (device, precision code) -> (versions, packed uint8 tensor)
+        self._packed = {}       # (device, precision code) -> _Packed
 
     # ---- packed-weight cache ------------------------------------------------
     def _fused_ok(self):
@@ -65,8 +157,9 @@ class Nerf(nn.Module):
     def packed_weights(self, precision=None):
         """Device buffer with the weight image the fused kernels stream; packs on
         first use and again after any in-place parameter update / reassignment."""
-        if not self._fused_ok():
-            raise RuntimeError("the fused HIP path is built for Nerf(Lp=10, Ld=4, H=256) only")
+        return self._packed_entry(precision).buf
+
+    def _packed_entry(self, precision=None):
         code = _lib.precision_code(self.precision if precision is None else precision)
         params = self._param_list()
         dev = params[0].device
@@ -75,8 +168,8 @@ class Nerf(nn.Module):
         key = (dev, code)
         stamp = tuple((p.data_ptr(), p._version) for p in params)
         hit = self._packed.get(key)
-        if hit is not None and hit[0] == stamp:
-            return hit[1]
+        if hit is not None and hit.stamp == stamp:
+            return hit
         lib = _lib.lib()
         with torch.no_grad():
             flat = torch.cat([p.detach().reshape(-1).float() for p in params])
@@ -86,8 +179,19 @@ class Nerf(nn.Module):
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(flat), _lib.ptr(packed), code,
                                                  _lib.stream_ptr(dev)), "nerf_amd_pack_weights")
-        self._packed[key] = (stamp, packed)
-        return packed
+        self._packed[key] = _Packed(stamp, packed)
+        return self._packed[key]
+
+    def _demote(self, entry, flags, where):
+        entry.demoted = True
+        why = []
+        if flags & _lib.STATUS_WEIGHT_RANGE:
+            why.append("a weight beyond 65504")
+        if flags & _lib.STATUS_NONFINITE:
+            why.append(f"a non-finite network output in {where}")
+        warnings.warn("Nerf: fp16 MFMA operands left their range (" + " and ".join(why) + "); these weights now render with "
+                      "bf16 operands (precision='bf16': fp32's exponent range, 8-bit mantissa) until they change",
+                      UserWarning, stacklevel=4)
 
     def repack_from_flat(self, flat):
         """Re-derive every packed image already in use from a flat fp32 parameter
@@ -100,19 +204,26 @@ class Nerf(nn.Module):
         with torch.cuda.device(dev):
             if _lib.BF16 in codes and _lib.BF16_BWD in codes:
                 # the training pair in one launch
-                a, b = self._packed[(dev, _lib.BF16)][1], self._packed[(dev, _lib.BF16_BWD)][1]
+                a, b = self._packed[(dev, _lib.BF16)].buf, self._packed[(dev, _lib.BF16_BWD)].buf
                 _lib.check(lib.nerf_amd_pack_weights_train(_lib.ptr(flat), _lib.ptr(a), _lib.ptr(b), _lib.stream_ptr(dev)),
                            "nerf_amd_pack_weights_train")
-                self._packed[(dev, _lib.BF16)] = (stamp, a)
-                self._packed[(dev, _lib.BF16_BWD)] = (stamp, b)
+                self._packed[(dev, _lib.BF16)] = _Packed(stamp, a)
+                self._packed[(dev, _lib.BF16_BWD)] = _Packed(stamp, b)
                 codes = codes - {_lib.BF16, _lib.BF16_BWD}
             for code in codes:
                 hit = self._packed.get((dev, code))
-                packed = hit[1] if hit is not None else torch.empty(
+                packed = hit.buf if hit is not None else torch.empty(
                     lib.nerf_amd_packed_bytes(code), dtype=torch.uint8, device=dev)
                 _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(flat), _lib.ptr(packed), code,
                                                      _lib.stream_ptr(dev)), "nerf_amd_pack_weights")
-                self._packed[(dev, code)] = (stamp, packed)
+                self._packed[(dev, code)] = _Packed(stamp, packed)       # new weights: the range guard starts over
+
+    def drop_packed(self, dev, keep=()):
+        """Forget the packed images of device ``dev`` except the precision codes in ``keep``: for callers that
+        update the parameters behind autograd's back (training.GraphedTrainStep re-packs only the images its
+        graphs use); the next use of a dropped image packs it again."""
+        for key in [k for k in self._packed if k[0] == dev and k[1] not in keep]:
+            del self._packed[key]
 
     # ---- forward ---------------------------------------------------------------
     def forward(self, v, *, precision=None):
@@ -126,15 +237,18 @@ class Nerf(nn.Module):
 
     def forward_inference(self, v, *, precision=None):
         code = _lib.precision_code(self.precision if precision is None else precision)
-        packed = self.packed_weights(code)
         v = v.detach().contiguous()
         P = v.shape[0]
-        out = torch.empty((P, 4), dtype=torch.float32, device=v.device)
-        with torch.cuda.device(v.device):
-            _lib.check(_lib.lib().nerf_amd_mlp_forward(_lib.ptr(v), _lib.ptr(packed), _lib.ptr(out),
-                                                       P, code, _lib.stream_ptr(v.device)),
-                       "nerf_amd_mlp_forward")
-        return out
+
+        def launch(code, packed):
+            out = torch.empty((P, 4), dtype=torch.float32, device=v.device)
+            with torch.cuda.device(v.device):
+                _lib.check(_lib.lib().nerf_amd_mlp_forward(_lib.ptr(v), _lib.ptr(packed[0]), _lib.ptr(out),
+                                                           P, code, _lib.stream_ptr(v.device)),
+                           "nerf_amd_mlp_forward")
+            return out
+
+        return guarded_launch([self], code, launch)
 
 
     def fp16_headroom(self, v):

@@ -19,7 +19,7 @@ from tqdm import tqdm
 
 from .. import _lib
 from .host_rng import ReferenceJitter, reference_rand
-from .nets import Nerf
+from .nets import Nerf, guarded_launch
 
 ALL_OUTPUTS = ("rgb", "disp", "alpha", "acc", "w")
 _tbins_cache = {}
@@ -38,11 +38,10 @@ def _tbins(tn, tf, N, device):
     return t
 
 
-def _sample_positions(u, tn, tf):
-    """ts from jitter with torch ops on u's device (generic-net fallback only)."""
-    N = u.shape[1]
-    t_bins = torch.linspace(tn, tf, N + 1).to(u.device)
-    return (t_bins[1] - t_bins[0]) * u + t_bins[:-1]
+def _per_sample(t_, N):
+    """alpha / w as the reference shapes them: [B,N], except [B,0] at N == 1, where its delta construction
+    leaves the sample axis empty (utils/rendering.py:60-61; the kernels reproduce rgb = acc = 0, disparity = NaN)."""
+    return t_ if (t_ is None or N != 1) else t_[:, :0]
 
 
 def volume_render(nerf_outs, ts, dirs, *, outputs=ALL_OUTPUTS):
@@ -72,7 +71,7 @@ def volume_render(nerf_outs, ts, dirs, *, outputs=ALL_OUTPUTS):
             _lib.ptr(raw), _lib.ptr(ts), _lib.ptr(dirs), 3, _lib.ptr(rgb), _lib.ptr(disp),
             _lib.ptr(alpha), _lib.ptr(acc), _lib.ptr(w), B, N, _lib.stream_ptr(dev)),
             "nerf_amd_volume_render")
-    return rgb, disp, alpha, acc, w
+    return rgb, disp, _per_sample(alpha, N), acc, _per_sample(w, N)
 
 
 def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUTS,
@@ -100,10 +99,10 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
     for name, t_ in (("ts", ts), ("u", u)):
         if t_ is not None and tuple(_lib.require_cuda_f32(t_, name).shape) != (B, N):
             raise RuntimeError("u / ts must be [B, N]")
-    code, packed = None, None
+    code = None
     if fused and not training:
         code = _lib.precision_code(net.precision if precision is None else precision)
-        packed = net.packed_weights(code)
+        net.packed_weights(code)              # packs now if it has to: errors surface before the jitter is drawn
 
     flags, jit, pending_rng = 0, None, None
     if ts is not None:
@@ -127,7 +126,7 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
     if not fused:
         return _render_generic(rays, net, N, tn, tf, jit, flags, outputs, seed, ray_id0)
 
-    try:
+    def launch(code, packed):
         lib = _lib.lib()
         rgb = torch.empty((B, 3), dtype=torch.float32, device=dev)
         disp = torch.empty((B,), dtype=torch.float32, device=dev)
@@ -138,36 +137,49 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
         ws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws else None
         with torch.cuda.device(dev):
             _lib.check(lib.nerf_amd_render_forward(
-                _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)), _lib.ptr(packed), code,
+                _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)), _lib.ptr(packed[0]), code,
                 flags, int(seed), int(ray_id0), _lib.ptr(rgb), _lib.ptr(disp), _lib.ptr(alpha),
                 _lib.ptr(acc), _lib.ptr(w), _lib.ptr(ws), B, N, _lib.stream_ptr(dev)), "nerf_amd_render_forward")
+        return rgb, disp, _per_sample(alpha, N), acc, _per_sample(w, N)
+
+    try:
+        return guarded_launch([net], code, launch)     # fp16: range guard (nets.guarded_launch)
     finally:
         if pending_rng is not None:
             pending_rng.finish()              # the render is enqueued behind it: only the generator kernel is awaited
-    return rgb, disp, alpha, acc, w
 
 
 render_rays = render_nerf      # the name BASELINE.json uses for the same function
 
 
 def _render_generic(rays, net, N, tn, tf, jit, flags, outputs, seed, ray_id0):
-    """Any other net object: assemble query points with torch ops on the GPU
-    (utils/rendering.py:31-40), call net.forward as the reference does (:41),
-    composite with the HIP kernel."""
-    B = rays.size(0)
-    if flags & _lib.FLAG_TS_GIVEN:
-        ts = jit
-    else:
-        if flags & _lib.FLAG_DEVICE_RNG:
-            g = torch.Generator(device=rays.device).manual_seed(int(seed) + int(ray_id0))
-            jit = torch.rand(B, N, device=rays.device, generator=g)
-        ts = _sample_positions(jit, tn, tf)
-    o, d = rays[:, :3], rays[:, 3:]
-    locs = o.unsqueeze(-1) + d.unsqueeze(-1) * ts.unsqueeze(1)
-    dn = d / torch.norm(d, dim=1, keepdim=True)
-    q = torch.cat((locs, dn.unsqueeze(-1).expand(-1, -1, N)), dim=1).permute(0, 2, 1).reshape(-1, 6)
-    out = net.forward(q).reshape(B, N, 4)
-    return volume_render(out.float(), ts, dn, outputs=outputs)
+    """Any other net object: sampling and query-point assembly in one HIP kernel (nerf_amd_query_points =
+    utils/rendering.py:24-40; the same jitter sources as the fused path, counter RNG included), the net's own
+    forward exactly as the reference calls it (:41), compositing by the HIP kernel with the directions taken
+    from the rays (:37,43).  Gradients flow to whatever ``net.forward`` attaches to its output."""
+    B, dev = rays.size(0), rays.device
+    lib = _lib.lib()
+    q = torch.empty((B * N, 6), dtype=torch.float32, device=dev)
+    ts = torch.empty((B, N), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.nerf_amd_query_points(_lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)), flags,
+                                             int(seed), int(ray_id0), _lib.ptr(q), _lib.ptr(ts), B, N,
+                                             _lib.stream_ptr(dev)), "nerf_amd_query_points")
+    out = net.forward(q).reshape(B, N, 4).float()
+    if torch.is_grad_enabled() and out.requires_grad:
+        from ..training import _VolumeRender
+        return _VolumeRender.apply(out, ts, rays, True)
+    out = out.detach().contiguous()
+    rgb = torch.empty((B, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((B,), dtype=torch.float32, device=dev)
+    acc = torch.empty((B,), dtype=torch.float32, device=dev)
+    alpha = torch.empty((B, N), dtype=torch.float32, device=dev) if "alpha" in outputs else None
+    w = torch.empty((B, N), dtype=torch.float32, device=dev) if "w" in outputs else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.nerf_amd_volume_render_rays(_lib.ptr(out), _lib.ptr(ts), _lib.ptr(rays), _lib.ptr(rgb), _lib.ptr(disp),
+                                                   _lib.ptr(alpha), _lib.ptr(acc), _lib.ptr(w), B, N, _lib.stream_ptr(dev)),
+                   "nerf_amd_volume_render_rays")
+    return rgb, disp, _per_sample(alpha, N), acc, _per_sample(w, N)
 
 
 def _render_batched(rays, net, batch_size, N, tn, tf, u, progress, id_base=0, **kw):
@@ -291,7 +303,7 @@ def render_view(net, pose, cam_params, *, N=128, tn=2, tf=6, u=None, ray0=0, n_r
     H, W, f = int(cam_params[0]), int(cam_params[1]), float(cam_params[2])
     n = H * W - ray0 if n_rays is None else int(n_rays)
     code = _lib.precision_code(net.precision if precision is None else precision)
-    packed = net.packed_weights(code)
+    net.packed_weights(code)
     flags, jit = 0, None
     if u is not None:
         jit = _lib.require_cuda_f32(u, "u").contiguous()
@@ -303,14 +315,18 @@ def render_view(net, pose, cam_params, *, N=128, tn=2, tf=6, u=None, ray0=0, n_r
     lib = _lib.lib()
     h_pose = np.zeros((3, 4), dtype=np.float32)
     h_pose[:] = np.asarray(pose, dtype=np.float32)[:3, :4]
-    pixels = torch.empty((n, 4), dtype=torch.float32, device=dev)
-    ws = torch.empty(max(int(lib.nerf_amd_render_image_workspace_bytes(code, n, N)), 256), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(lib.nerf_amd_render_image_forward(
-            h_pose.ctypes.data, H, W, f, int(ray0), n, _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)),
-            _lib.ptr(packed), code, flags, int(seed), _lib.ptr(pixels), _lib.ptr(ws), int(N),
-            _lib.stream_ptr(dev)), "nerf_amd_render_image_forward")
-    return pixels
+
+    def launch(code, packed):
+        pixels = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(int(lib.nerf_amd_render_image_workspace_bytes(code, n, N)), 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_render_image_forward(
+                h_pose.ctypes.data, H, W, f, int(ray0), n, _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, N, dev)),
+                _lib.ptr(packed[0]), code, flags, int(seed), _lib.ptr(pixels), _lib.ptr(ws), int(N),
+                _lib.stream_ptr(dev)), "nerf_amd_render_image_forward")
+        return pixels
+
+    return guarded_launch([net], code, launch)
 
 
 def render_view_sharded(net, pose, cam_params, *, group=None, **kw):
@@ -366,7 +382,7 @@ def render_hierarchical(rays, net_coarse, net_fine, Nc=64, Nf=128, tn=2, tf=6, *
     dev, B = rays.device, rays.size(0)
     rays = rays.detach().contiguous()
     code = _lib.precision_code(net_coarse.precision if precision is None else precision)
-    packed = net_coarse.packed_weights(code)
+    net_coarse.packed_weights(code)
     flags, jit = _lib.FLAG_DEVICE_RNG, None
     if u_c is None and not device_rng:
         u_c, pending_rng = reference_rand(B, Nc, dev)
@@ -375,17 +391,21 @@ def render_hierarchical(rays, net_coarse, net_fine, Nc=64, Nf=128, tn=2, tf=6, *
         flags, jit = 0, _lib.require_cuda_f32(u_c, "u_c").contiguous()
     # the coarse pass through the stage-1 entry point: the sampler needs the positions the kernel drew
     lib = _lib.lib()
-    raw = torch.empty((B, Nc, 4), dtype=torch.float32, device=dev)
-    ts_c = torch.empty((B, Nc), dtype=torch.float32, device=dev)
-    outs = [torch.empty(s_, dtype=torch.float32, device=dev) for s_ in ((B, 3), (B,), (B, Nc), (B,), (B, Nc))]
-    with torch.cuda.device(dev):
-        st = _lib.stream_ptr(dev)
-        _lib.check(lib.nerf_amd_mlp_forward_rays(
-            _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, Nc, dev)), _lib.ptr(packed), code, flags, int(seed),
-            int(ray_id0), _lib.ptr(raw), _lib.ptr(ts_c), B, Nc, st), "nerf_amd_mlp_forward_rays")
-        _lib.check(lib.nerf_amd_volume_render_rays(_lib.ptr(raw), _lib.ptr(ts_c), _lib.ptr(rays),
-                                                   *[_lib.ptr(x) for x in outs], B, Nc, st), "nerf_amd_volume_render_rays")
-    coarse = tuple(outs)
+
+    def launch(code, packed):
+        raw = torch.empty((B, Nc, 4), dtype=torch.float32, device=dev)
+        ts_c = torch.empty((B, Nc), dtype=torch.float32, device=dev)
+        outs = [torch.empty(s_, dtype=torch.float32, device=dev) for s_ in ((B, 3), (B,), (B, Nc), (B,), (B, Nc))]
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr(dev)
+            _lib.check(lib.nerf_amd_mlp_forward_rays(
+                _lib.ptr(rays), _lib.ptr(jit), _lib.ptr(_tbins(tn, tf, Nc, dev)), _lib.ptr(packed[0]), code, flags, int(seed),
+                int(ray_id0), _lib.ptr(raw), _lib.ptr(ts_c), B, Nc, st), "nerf_amd_mlp_forward_rays")
+            _lib.check(lib.nerf_amd_volume_render_rays(_lib.ptr(raw), _lib.ptr(ts_c), _lib.ptr(rays),
+                                                       *[_lib.ptr(x) for x in outs], B, Nc, st), "nerf_amd_volume_render_rays")
+        return ts_c, tuple(outs)
+
+    ts_c, coarse = guarded_launch([net_coarse], code, launch)
     ts_f = sample_pdf(ts_c, coarse[4], Nf, u=u_f, device_rng=device_rng, seed=seed, ray_id0=ray_id0)
     fine = render_nerf(rays, net_fine, Nc + Nf, tn, tf, ts=ts_f, precision=precision)
     return fine, coarse, ts_f
@@ -405,7 +425,6 @@ def render_hierarchical_view(net_coarse, net_fine, pose, cam_params, Nc=64, Nf=1
     H, W, f = int(cam_params[0]), int(cam_params[1]), float(cam_params[2])
     n = H * W - ray0 if n_rays is None else int(n_rays)
     code = _lib.precision_code(net_coarse.precision if precision is None else precision)
-    pc, pf = net_coarse.packed_weights(code), net_fine.packed_weights(code)
     flags = 0
     if device_rng:
         flags, u_c, u_f = _lib.FLAG_DEVICE_RNG, None, None
@@ -421,14 +440,20 @@ def render_hierarchical_view(net_coarse, net_fine, pose, cam_params, Nc=64, Nf=1
     lib = _lib.lib()
     h_pose = np.zeros((3, 4), dtype=np.float32)
     h_pose[:] = np.asarray(pose, dtype=np.float32)[:3, :4]
-    pixels = torch.empty((n, 4), dtype=torch.float32, device=dev)
-    ws = torch.empty(max(int(lib.nerf_amd_render_hierarchical_workspace_bytes(n, Nc, Nf)), 256), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(lib.nerf_amd_render_hierarchical_forward(
-            h_pose.ctypes.data, H, W, f, int(ray0), n, _lib.ptr(u_c), _lib.ptr(u_f), _lib.ptr(_tbins(tn, tf, Nc, dev)),
-            _lib.ptr(pc), _lib.ptr(pf), code, flags, int(seed), _lib.ptr(pixels), _lib.ptr(ws), int(Nc), int(Nf),
-            _lib.stream_ptr(dev)), "nerf_amd_render_hierarchical_forward")
-    return pixels
+
+    def launch(code, packed):
+        pixels = torch.empty((n, 4), dtype=torch.float32, device=dev)
+        ws = torch.empty(max(int(lib.nerf_amd_render_hierarchical_workspace_bytes(n, Nc, Nf)), 256), dtype=torch.uint8,
+                         device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.nerf_amd_render_hierarchical_forward(
+                h_pose.ctypes.data, H, W, f, int(ray0), n, _lib.ptr(u_c), _lib.ptr(u_f), _lib.ptr(_tbins(tn, tf, Nc, dev)),
+                _lib.ptr(packed[0]), _lib.ptr(packed[-1]), code, flags, int(seed), _lib.ptr(pixels), _lib.ptr(ws), int(Nc),
+                int(Nf), _lib.stream_ptr(dev)), "nerf_amd_render_hierarchical_forward")
+        return pixels
+
+    # one precision for both passes: if either network left the fp16 range, both render with bf16 operands
+    return guarded_launch([net_coarse] if net_fine is net_coarse else [net_coarse, net_fine], code, launch)
 
 
 def render_hierarchical_sharded(net_coarse, net_fine, pose, cam_params, Nc=64, Nf=128, *, group=None, **kw):

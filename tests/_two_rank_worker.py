@@ -47,16 +47,23 @@ def main():
     tnet.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
     parallel.broadcast_parameters(tnet)
     opt = FusedAdam(tnet, lr=5e-4)
-    stepper = GraphedTrainStep(tnet, opt, half, N, group=dist.group.WORLD)
+    stepper = GraphedTrainStep(tnet, opt, half, N, group=dist.group.WORLD, timing=True)
+    assert stepper.bucketed and stepper.graph_a2 is not None          # two gradient launches, two overlapped exchanges
     loss = stepper.step(rays[sl].to(dev), gt[sl].to(dev), u=uu[sl].to(dev))
     torch.cuda.synchronize()
     res["grads"] = stepper.grads.cpu().numpy()
     res["loss"] = np.array([float(loss)])
     res["params"] = opt.flat.cpu().numpy()
+    for _ in range(3):                                                # replays: the exchange pattern repeats cleanly
+        stepper.step(rays[sl].to(dev), gt[sl].to(dev), u=uu[sl].to(dev))
+    span, exposed = stepper.collective_times()
+    assert span >= exposed >= 0.0
+    res["params4"] = opt.flat.cpu().numpy()
+    res["collective_ms"] = np.array([span, exposed])
     if rank == 0:
         np.savez(os.path.join(out_dir, "rank0.npz"), **res)
     else:
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=res["loss"], params=res["params"])
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=res["loss"], params=res["params"], params4=res["params4"])
     dist.barrier()
     dist.destroy_process_group()
 

@@ -362,7 +362,7 @@ def g8_trajectory(rays_tab, gt_tab):
         torch.set_rng_state(st)
         return np_(torch.mean((rgb - val_gt) ** 2))
 
-    grad_sets = []
+    grad_sets, snaps = [], {}
     for seed in G8_SEEDS:
         net = rnets.Nerf()
         net.load_state_dict(sd, strict=True)
@@ -389,6 +389,7 @@ def g8_trajectory(rays_tab, gt_tab):
             losses.append(np_(loss))
             if i + 1 in G8_CHECKPOINTS:
                 vals.append(val_mse(net))
+                snaps[(seed, i + 1)] = torch.cat([p.detach().reshape(-1) for p in net.parameters()]).clone()
                 if seed == G8_SEEDS[0]:
                     _store_params(out, net, tag=f"step{i + 1}")
         out[f"loss/{seed}"] = np.asarray(losses, dtype=np.float32)
@@ -399,6 +400,12 @@ def g8_trajectory(rays_tab, gt_tab):
         print(f"  G8 seed {seed}: loss {float(losses[0]):.5f} -> {float(losses[-1]):.5f}, val {[float(v) for v in vals]}")
     for k, v in _minibatch_std(grad_sets).items():
         out[f"mbstd/{k}"] = np.float64(v)
+    # the reference's own run-to-run spread in parameter space: distance between the runs of two seeds over the
+    # distance the first one has travelled from the initial weights, all 595,844 parameters
+    p0 = torch.cat([v.reshape(-1) for v in sd.values()])
+    for c in G8_CHECKPOINTS:
+        a = snaps[(G8_SEEDS[0], c)]
+        out[f"seedspread/step{c}"] = np.float64(min(float((snaps[(s_, c)] - a).norm() / (a - p0).norm()) for s_ in G8_SEEDS[1:]))
     save("trajectory.npz", **out)
 
 

@@ -1,0 +1,230 @@
+"""GPU tests of the boundary's edges: the fp16 range guard, the reference's degenerate
+N = 1 result, a reference-format checkpoint through utils/checkpoint on the GPU, a foreign ``net`` object."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    from nerf_simple_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def scene_rays(oracle, synthetic, side=12):
+    pose = torch.from_numpy(oracle.spherical_to_pose(4, -30, 0)).float()
+    return oracle.camera_rays(pose, [side, side, synthetic.focal_from_fov(side)]).contiguous()
+
+
+def high_gain_state_dict(synthetic, gain):
+    """The structured weights with the first hidden layer scaled up by ``gain`` and the second layer's weights scaled
+    down by it: ReLU is positively homogeneous, so the network computes the same function in exact arithmetic, but its
+    first hidden activations are ``gain`` times larger -- far beyond fp16's 65504 for gain = 1e5, while every weight
+    stays finite in fp16.  The fp32 reference and bf16 operands (fp32's exponent range) are indifferent to it."""
+    sd = {k: v.clone() for k, v in synthetic.synthetic_state_dict(0, "structured").items()}
+    sd["layers_0.0.weight"] *= gain
+    sd["layers_0.0.bias"] *= gain
+    sd["layers_0.2.weight"] /= gain
+    return sd
+
+
+def test_fp16_overflow_is_never_silent(dev, oracle, synthetic):
+    """Weights whose hidden activations exceed 65504: the default (fp16) render must not hand out NaN pixels silently.
+    The first render with such weights warns, demotes the module to bf16 operands for these weights and returns the
+    bf16 render; the raw C ABI call shows what would have happened (non-finite pixels + the sticky status bit)."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import render_nerf
+    lib = _lib.lib()
+    rays = scene_rays(oracle, synthetic).to(dev)
+    B, N = rays.shape[0], 64
+    u = torch.rand(B, N, generator=torch.Generator().manual_seed(3)).to(dev)
+    sd = high_gain_state_dict(synthetic, 1e5)
+    with torch.no_grad():
+        want = oracle.render_nerf(rays.cpu(), sd, N, u=u.cpu())
+    assert torch.isfinite(want[0]).all()                   # the fp32 reference has no problem with these weights
+    net = Nerf().to(dev)                                   # default precision: fp16
+    assert net.precision == "fp16"
+    net.load_state_dict(sd)
+    # the kernel itself, through the C ABI: non-finite pixels and the status bit
+    from nerf_simple_amd.utils.nets import packed_status
+    packed = net.packed_weights(_lib.FP16)
+    assert packed_status(packed, _lib.FP16) == 0
+    rgb, disp, acc = torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
+    tb = torch.linspace(2, 6, N + 1).to(dev)
+    _lib.check(lib.nerf_amd_render_forward(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tb), _lib.ptr(packed), _lib.FP16, 0, 0, 0,
+                                           _lib.ptr(rgb), _lib.ptr(disp), None, _lib.ptr(acc), None, None, B, N,
+                                           _lib.stream_ptr(dev)), "render")
+    # The pixels are wrong but need not even be NaN: the kernel's integer ReLU turns a NaN with the sign bit set into 0,
+    # and a layer whose rows are all NaN comes out as zeros -- finite garbage from there on.  The status word is set
+    # all the same, from the accumulators (mlp_bf16_16.hip epilogue_piece).
+    assert float((rgb.cpu() - want[0]).abs().max()) > 0.2 or not torch.isfinite(rgb).all()
+    assert packed_status(packed, _lib.FP16) == _lib.STATUS_NONFINITE
+    # bf16 operands on the same weights: the flag stays clear
+    pb = net.packed_weights(_lib.BF16)
+    _lib.check(lib.nerf_amd_render_forward(_lib.ptr(rays), _lib.ptr(u), _lib.ptr(tb), _lib.ptr(pb), _lib.BF16, 0, 0, 0,
+                                           _lib.ptr(rgb), _lib.ptr(disp), None, _lib.ptr(acc), None, None, B, N,
+                                           _lib.stream_ptr(dev)), "render")
+    assert packed_status(pb, _lib.BF16) == 0 and torch.isfinite(rgb).all()
+    # the host wrapper: warning + bf16 result, never the NaN pixels
+    net2 = Nerf().to(dev)
+    net2.load_state_dict(sd)
+    with torch.no_grad():
+        with pytest.warns(UserWarning, match="fp16 MFMA operands left their range"):
+            got = render_nerf(rays, net2, N, u=u)
+        bf = render_nerf(rays, net2, N, u=u, precision="bf16")
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                 # demoted already: no second warning, same bf16 kernels
+            again = render_nerf(rays, net2, N, u=u)
+            out = net2(rays.new_zeros(8, 6) + 0.1)         # Nerf.forward is guarded by the same state
+    for a, b, c in zip(got, bf, again):
+        assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
+        assert np.array_equal(a.cpu().numpy(), c.cpu().numpy(), equal_nan=True)
+    # finite like the fp32 reference: everything but the disparity of rays that accumulate nothing (acc == 0 -> 0/0)
+    for k in (0, 2, 3, 4):
+        assert torch.isfinite(got[k]).all() and torch.isfinite(want[k]).all()
+    assert torch.equal(torch.isnan(got[1]), got[3] == 0) and torch.equal(torch.isnan(want[1]), want[3] == 0)
+    assert torch.isfinite(out).all()
+    err = float((got[0].cpu() - want[0]).abs().max())
+    print("high-gain weights, bf16 fallback: max |rgb err| vs the fp32 oracle", err)
+    assert err <= 4.5e-2 * max(1.0, float(want[0].abs().max()))      # the bf16 tolerance of tests/test_gpu_parity.py
+    # new weights: the guard starts over, and sane weights stay in fp16 without a warning
+    net2.load_state_dict(synthetic.synthetic_state_dict(0, "structured"))
+    with torch.no_grad(), warnings.catch_warnings():
+        warnings.simplefilter("error")
+        a = render_nerf(rays, net2, N, u=u)
+        b = render_nerf(rays, net2, N, u=u, precision="fp16")
+        c = render_nerf(rays, net2, N, u=u, precision="bf16")
+    assert torch.equal(a[0], b[0]) and not torch.equal(a[0], c[0])
+
+
+def test_fp16_weight_out_of_range_flagged_at_pack(dev, synthetic):
+    """A single weight beyond 65504 (finite in fp32) is flagged by the packer itself."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.nets import Nerf
+    lib = _lib.lib()
+    sd = {k: v.clone() for k, v in synthetic.synthetic_state_dict(0, "default").items()}
+    sd["layers_1.0.weight"][3, 5] = 7.0e4
+    net = Nerf().to(dev)
+    net.load_state_dict(sd)
+    from nerf_simple_amd.utils.nets import packed_status
+    for code, want in ((_lib.FP16, _lib.STATUS_WEIGHT_RANGE), (_lib.BF16, 0)):
+        assert packed_status(net.packed_weights(code), code) == want
+    v = synthetic.points_in_scene(64, seed=2).to(dev)
+    with torch.no_grad():
+        with pytest.warns(UserWarning, match="a weight beyond 65504"):
+            out = net(v)
+        assert torch.equal(out, net(v, precision="bf16"))
+
+
+def test_single_sample_matches_the_reference(dev, oracle, synthetic):
+    """N = 1: the reference's delta construction leaves the sample axis empty (utils/rendering.py:60-61), so
+    render_nerf returns rgb = 0, disparity = NaN, acc = 0 and alpha / w of shape [B,0], still drawing its
+    torch.rand(B,1) -- checked against the oracle (whose torch ops do exactly that) for every precision, the
+    standalone compositor, and the training path (all gradients exactly zero)."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import render_nerf, volume_render
+    rays = scene_rays(oracle, synthetic, 5)
+    B = rays.shape[0]
+    sd = synthetic.synthetic_state_dict(0, "structured")
+    saved = torch.get_rng_state()
+    try:
+        torch.manual_seed(5)
+        with torch.no_grad():
+            want = oracle.render_nerf(rays, sd, 1)
+        want_next = torch.rand(3)
+        assert want[2].shape == (B, 0) and want[4].shape == (B, 0) and torch.isnan(want[1]).all()
+        for precision in ("fp32", "fp16", "bf16"):
+            net = Nerf(precision=precision).to(dev)
+            net.load_state_dict(sd)
+            torch.manual_seed(5)
+            with torch.no_grad():
+                got = render_nerf(rays.to(dev), net, 1)
+            assert torch.equal(torch.rand(3), want_next), precision       # the same draw from the CPU generator
+            for a, b in zip(got, want):
+                assert a.shape == b.shape, precision
+                assert np.array_equal(a.cpu().numpy(), b.numpy(), equal_nan=True), precision
+    finally:
+        torch.set_rng_state(saved)
+    raw = torch.randn(B, 1, 4)
+    ts = torch.rand(B, 1) + 2
+    d = torch.randn(B, 3)
+    want = oracle.volume_render(raw, ts, d)
+    got = volume_render(raw.to(dev), ts.to(dev), d.to(dev))
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and np.array_equal(a.cpu().numpy(), b.numpy(), equal_nan=True)
+    # training at N = 1: the reference's loss does not depend on the network, its gradients are exact zeros
+    net = Nerf(precision="bf16").to(dev)
+    net.load_state_dict(sd)
+    rgb = render_nerf(rays.to(dev), net, 1, u=torch.rand(B, 1).to(dev))[0]
+    assert rgb.requires_grad
+    rgb.pow(2).sum().backward()
+    for k, p in net.named_parameters():
+        assert p.grad is not None and float(p.grad.abs().max()) == 0.0, k
+
+
+def test_reference_checkpoint_renders_g5(dev, golden, oracle, synthetic, tmp_path):
+    """N4 on the GPU: a .pth in the reference's format (torch.save(net.state_dict()), train.py:84-91) written by the
+    reference-side recipe, loaded through utils/checkpoint.load_checkpoint (strict, weights_only), renders golden G5
+    (the 100x100x32 image) with the fp32 kernel."""
+    from nerf_simple_amd.utils import checkpoint
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import render_poses
+    g = golden("image_structured.npz")
+    path = str(tmp_path / "1666742866.6157136.pth")
+    torch.save({k: v.clone() for k, v in synthetic.synthetic_state_dict(0, "structured").items()}, path)
+    net = checkpoint.load_checkpoint(Nerf(precision="fp32").to(dev), path)
+    assert next(net.parameters()).is_cuda
+    u = t(golden("image_u.npz")["u"]).to(dev)
+    pose = t(g["pose"])
+    rgb, disp = render_poses(net, [pose], [100, 100, float(g["f"])], int(g["batch_size"]), N=32, u=u)
+    assert np.abs(rgb[0].reshape(-1, 3) - g["rgb"]).max() <= 1e-4
+    assert np.abs(disp[0].reshape(-1) - g["disp"]).max() <= 1e-4 * max(1.0, float(np.abs(g["disp"]).max()))
+    # and back: a checkpoint written here holds the reference's 24 keys with the trained values
+    out = checkpoint.save_checkpoint(net, str(tmp_path / "out.pth"))
+    sd = torch.load(out, weights_only=True)
+    assert list(sd.keys()) == [k for k, _ in synthetic.PARAM_SPECS]
+    assert all(torch.equal(sd[k], v) for k, v in synthetic.synthetic_state_dict(0, "structured").items())
+
+
+def test_foreign_net_path_is_the_same_arithmetic(dev, golden, synthetic):
+    """render_nerf with an arbitrary ``net`` object (utils/rendering.py:41 calls net.forward on whatever it is given):
+    sampling and query points come from nerf_amd_query_points, the net runs as given, nerf_amd_volume_render_rays
+    composites.  With the fp32 kernel behind the foreign object the result equals the fused one-launch render bit
+    for bit -- explicit jitter and the counter RNG alike -- and gradients reach a foreign torch module."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import render_nerf
+    g = golden("render_structured.npz")
+    net = Nerf(precision="fp32").to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "structured"))
+    seen = {}
+
+    class Wrapped:
+        def forward(self, q):
+            seen["shape"] = tuple(q.shape)
+            return net.forward_inference(q)
+
+    rays = t(g["rays"]).to(dev)
+    u = t(g["N64_u"]).to(dev)
+    with torch.no_grad():
+        for kw in (dict(u=u), dict(device_rng=True, seed=11, ray_id0=1000)):
+            a = render_nerf(rays, Wrapped(), 64, **kw)
+            b = render_nerf(rays, net, 64, **kw)
+            assert seen["shape"] == (rays.shape[0] * 64, 6)
+            for x, y in zip(a, b):
+                assert torch.equal(x, y)
+    tiny = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4)).to(dev)
+    rgb = render_nerf(rays[:32], tiny, 16, u=torch.rand(32, 16, device=dev))[0]
+    rgb.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in tiny.parameters())
+    assert float(tiny[0].weight.grad.abs().max()) > 0

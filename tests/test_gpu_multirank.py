@@ -92,6 +92,11 @@ def test_data_parallel_step_equals_global_batch(two_rank_results, golden, synthe
     assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), np.abs(got - want).max() / np.abs(want).max()
     assert abs(0.5 * (float(r0["loss"][0]) + float(r1["loss"][0])) - loss) <= 1e-5 * loss
     assert np.array_equal(r0["params"], r1["params"])
+    # the step reduces the gradient in two buckets, the first one beside the second gradient launch; three more
+    # replays leave both ranks with identical, finite parameters that moved
+    assert np.array_equal(r0["params4"], r1["params4"]) and np.isfinite(r0["params4"]).all()
+    assert not np.array_equal(r0["params4"], r0["params"])
+    print("2-rank gloo exchange: span / exposed ms", r0["collective_ms"])
 
 
 @pytest.mark.parametrize("mode", ["render", "train"])
@@ -110,3 +115,5 @@ def test_bench_self_launch_two_ranks(mode):
     assert res["n_gpus"] == 2 and res["ranks"]["world_size"] == 2 and res["ranks"]["rank_sum_check"] is True
     assert res["value"] > 0 and res["steps"] == 2
     assert res["scaling"] == ("strong" if mode == "render" else "weak")
+    assert res["collective_ms"] > 0 and len(res["kernel_ms_per_rank"]) == 2
+    assert res["ranks"]["backend"] == "gloo" and res["ranks"]["devices_distinct"] is False      # the rehearsal shares one GPU

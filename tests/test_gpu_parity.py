@@ -366,6 +366,10 @@ def test_fused_render_random_shapes(dev, synthetic):
                                                7 * k, *[_lib.ptr(x) for x in one], None, B, N, st), "render_forward")
         torch.cuda.synchronize()
         for n, a, b in zip(NAMES, one, two):
+            if N == 1 and n in ("alpha", "w"):
+                # the reference's sample axis is empty at N == 1 (utils/rendering.py:60-61): nothing is written
+                assert bool((a == -7.0).all()), (B, N, flags, n)
+                continue
             same = torch.equal(a, b) or bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all())
             assert same, (B, N, flags, n)
 

@@ -38,9 +38,22 @@ def test_header_symbols_exported(lib):
 
 
 def test_introspection(lib):
-    assert lib.nerf_amd_abi_version() == 2
+    assert lib.nerf_amd_abi_version() == 3
     assert lib.nerf_amd_param_count() == 595844
-    assert lib.nerf_amd_packed_bytes(1) == lib.nerf_amd_packed_bytes(2) == 1172 * 1024 + 2464 * 4
+    # 16-bit images: weights, bias table, 256-byte status block (the fp16 range guard's sticky flags)
+    assert lib.nerf_amd_packed_bytes(1) == lib.nerf_amd_packed_bytes(2) == 1172 * 1024 + 2464 * 4 + 256
+    assert lib.nerf_amd_packed_status_offset(1) == lib.nerf_amd_packed_status_offset(2) == 1172 * 1024 + 2464 * 4
+    assert lib.nerf_amd_packed_status_offset(0) == -1 and lib.nerf_amd_packed_status_offset(3) == -1
+    first, count = ctypes.c_int64(), ctypes.c_int64()
+    ranges = []
+    for bucket in (0, 1, 2):
+        assert lib.nerf_amd_grad_bucket_range(bucket, ctypes.byref(first), ctypes.byref(count)) == 0
+        ranges.append((first.value, count.value))
+    assert ranges[0] == (0, 595844)
+    # bucket 2 = layers_0.* (the head of the flat vector), bucket 1 = everything behind it
+    head = 256 * 63 + 256 + 4 * (256 * 256 + 256)
+    assert ranges[2] == (0, head) and ranges[1] == (head, 595844 - head)
+    assert lib.nerf_amd_grad_bucket_range(3, ctypes.byref(first), ctypes.byref(count)) < 0
     assert lib.nerf_amd_packed_bytes(0) == 2360 * 1024 + 154 * 16 * 4
     assert lib.nerf_amd_packed_bytes(7) < 0
     for prec in (0, 1, 2):                                                              # one fused launch: no workspace
@@ -114,6 +127,28 @@ def test_state_dict_contract(synthetic):
     assert sum(p.numel() for p in net.parameters()) == 595844
 
 
+def test_unsupported_network_shapes_raise_at_construction():
+    """The kernels implement the one shape the reference constructs (Nerf() at train.py:41, test.py:27); any other
+    (Lp, Ld, H) is refused when the module is built, not when its forward first runs."""
+    from nerf_simple_amd.utils.nets import Nerf
+    Nerf(10, 4, 256)
+    for args in ((6, 4, 256), (10, 2, 256), (10, 4, 128)):
+        with pytest.raises(RuntimeError, match="unsupported configuration"):
+            Nerf(*args)
+
+
+def test_oracle_single_sample_is_the_reference_degenerate_case(oracle, synthetic):
+    """N = 1 in the reference (verified by running it: utils/rendering.py:60-61 builds deltas from an empty
+    difference): empty sample axis, rgb = acc = 0, disparity NaN.  The oracle issues the same torch ops; the GPU
+    tests hold the kernels to this."""
+    import torch
+    rays = torch.tensor([[0., 0, 4, 0.1, 0.2, -1.0], [0., 0, 4, -0.1, 0.0, -1.0]])
+    with torch.no_grad():
+        rgb, disp, alpha, acc, w = oracle.render_nerf(rays, synthetic.synthetic_state_dict(0, "default"), 1)
+    assert alpha.shape == (2, 0) and w.shape == (2, 0)
+    assert float(rgb.abs().max()) == 0 and float(acc.abs().max()) == 0 and torch.isnan(disp).all()
+
+
 def test_host_camera_helpers(golden):
     import torch
     import numpy as np
@@ -157,7 +192,10 @@ def test_abi_argument_errors(lib):
     # point-blocked bf16 activations (10 layers x ceil(P/256) tiles x 128 KiB) + ReLU mask bits (.. x 8 KiB)
     assert lib.nerf_amd_train_activation_bytes(1000) == 10 * 4 * (131072 + 8192)
     assert lib.nerf_amd_packed_bytes(3) == 1112 * 1024
-    assert lib.nerf_amd_packed_bytes(2) == 1172 * 1024 + 2464 * 4
+    assert lib.nerf_amd_packed_bytes(2) == 1172 * 1024 + 2464 * 4 + 256
+    assert lib.nerf_amd_query_points(one, null, one, 0, 0, 0, one, null, 4, 8, null) == EINVAL        # no jitter
+    assert lib.nerf_amd_query_points(null, null, null, 0, 0, 0, null, null, 0, 8, null) == 0           # no rays: nothing to do
+    assert lib.nerf_amd_param_gradients_finish_bucket(one, one, one, one, one, one, 16, 3, null) == EINVAL   # buckets are 0, 1, 2
 
 
 def test_checkpoint_roundtrip(tmp_path, synthetic):

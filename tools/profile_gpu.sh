@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-aux $*"
 run() {   # run <subdir> <rocprofv3 options...>
   local sub=$1; shift
   rocprofv3 "$@" --output-format csv -d $OUT/$sub -- python3 $REPO/bench.py $ARGS > $OUT/$sub.log 2>&1 || echo "$sub failed"
@@ -21,5 +21,5 @@ run pmc_fetch --kernel-trace --pmc FETCH_SIZE
 run pmc_write --kernel-trace --pmc WRITE_SIZE
 # keep only the small summaries
 find $OUT -name "*.csv" -size +2M -delete
-python3 $REPO/tools/summarize_prof.py $OUT > $OUT/SUMMARY.txt 2>&1 || true
+BENCH_ARGS="$*" python3 $REPO/tools/summarize_prof.py $OUT > $OUT/SUMMARY.txt 2>&1 || true
 cat $OUT/SUMMARY.txt
