@@ -125,6 +125,7 @@ struct State {
     f32x4 pend[NCB][2];               // [column block][tile of the pending pair]
     float sigma[NCB], rgb[NCB][3];
     bool bad;                         // range guard: a non-finite accumulator was seen (flag_nonfinite)
+    unsigned posd_off[NCB];           // LDS address of this lane's direction fragment (stage_inputs)
     // training forward only (SAVE): where this lane's activations go
     char* acts;
     long long P;
@@ -299,7 +300,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
     static_assert(PL < 0 || PL == L || (PL == 8 && PQ == 8) || NCB * PQ >= PEND_M0 + 4 * NCB / PEND_PER,
                   "pending pair finished too late");
     const unsigned wb = c.b_wread[CC & 1];
-    const unsigned xb = D.extra_kind == 1 ? c.b_posx : c.b_posd;
+    const unsigned xb = c.b_posx;
     // the chunk that runs next (cyclic: the last chunk of a tile prefetches the first one of the next tile)
     constexpr int NCC = (CC + 1) % NUM_CHUNKS;
     constexpr int NL = chunk_layer(NCC);
@@ -346,7 +347,8 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int e = 0; e < KS_EXTRA; ++e) bx[cb][e] = lds_load<ex8>(xb, cb * XBLK + e * 1024);
+            for (int e = 0; e < KS_EXTRA; ++e)
+                bx[cb][e] = D.extra_kind == 1 ? lds_load<ex8>(xb, cb * XBLK + e * 1024) : lds_load<ex8>(st.posd_off[cb], e * 1024);
     }
     f32x4 acc[NCB][NT];
     // register i of lane group g is row 16*rt + 4g + i: one 16-B bias read per tile
@@ -468,6 +470,33 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
     }
     const long long p_end = COMP ? st.p_end : a.P;
     const int last_local = (int)(p_end - 1 - tile_base);  // lanes past the end use the last point (results dropped)
+    // The direction features (posd: 24 sines / cosines, 3 raw coordinates) belong to the RAY:
+    // in rays mode they are evaluated once per ray of the tile -- one LDS slot of 64 B per ray, value (group g, slot s)
+    // by thread 32 * ray + 8 g + s, two rays per tile at N = 128 -- instead of once per sample, and with them goes
+    // the per-sample normalisation of the direction (a square root and three exact divisions).  Every lane then
+    // reads its ray's 16-byte fragment (a broadcast within the 16 points of a column block).  Same operations per
+    // value as the per-sample form: bit-identical features.  (The training forward keeps the per-sample form: it
+    // also serves explicit points, whose directions are per point.)
+    constexpr bool RAY_POSD = RAYS && !SAVE;
+    if constexpr (RAY_POSD) {
+        const int top = last_local < TILE_PTS - 1 ? last_local : TILE_PTS - 1;
+        const int nrays = (int)(split_point(b0, r0, top, a.N).b - b0) + 1;          // rays this tile touches (uniform)
+        for (int idx = threadIdx.x; idx < nrays * 32; idx += WAVES * 64) {
+            const int ray = idx >> 5, slot = idx & 31, gg = slot >> 3, sl = slot & 7;
+            const float* rp = a.rays + (b0 + ray) * 6 + 3;
+            const float dx = rp[0], dy = rp[1], dz = rp[2];
+            const float nrm = norm3(dx, dy, dz);              // as fetch_point_rays normalises: torch.norm bit for bit
+            float val = 0.f;
+            if (sl < 6) {                                     // posd_col_f32: per coordinate the pair (level g, trig)
+                const int cd = sl >> 1;
+                const float dc = __fdiv_rn(cd == 0 ? dx : cd == 1 ? dy : dz, nrm);
+                val = enc_lane(to_revolutions(dc), 2 * gg + (sl & 1));
+            } else if (sl == 6 && gg < 3) {
+                val = __fdiv_rn(gg == 0 ? dx : gg == 1 ? dy : dz, nrm);
+            }
+            lds_store<elem_t>(LDS_POSD + ray * 64 + slot * 2, 0, (elem_t)val);
+        }
+    }
     if constexpr (RAYS && NCB == 2) {
         dev_rng = (a.flags & NERF_FLAG_DEVICE_RNG) && !(a.flags & NERF_FLAG_TS_GIVEN);
         if (dev_rng) {
@@ -483,6 +512,7 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
         st.loff[cb] = valid ? block_lane_offset(g, c.wave * (16 * NCB) + cb * 16 + col) : LOFF_INVALID;
         if (!valid) p = p_end - 1;
         PointIn pt;
+        st.posd_off[cb] = c.b_posd + cb * 1024;              // per-sample form: this lane's own fragment
         if constexpr (RAYS) {
             const float u_cb = (NCB == 2) ? __shfl(u_mine, cb * 16 + col) : 0.f;
             int lp = c.wave * (16 * NCB) + cb * 16 + col;
@@ -490,7 +520,9 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
             if (SAVE && a.pts) {
                 pt = fetch_point_pts(a, p);
             } else {
-                pt = fetch_point_rays(a, p, split_point(b0, r0, lp, a.N), u_cb, dev_rng);
+                const RaySample rs = split_point(b0, r0, lp, a.N);
+                if constexpr (RAY_POSD) st.posd_off[cb] = LDS_POSD + (unsigned)(rs.b - b0) * 64 + g * 16;
+                pt = fetch_point_rays<!RAY_POSD>(a, p, rs, u_cb, dev_rng);
                 if constexpr (COMP) {
                     if (valid && g == 0)
                         lds_store<float>(((st.ring_q0 + c.wave * (16 * NCB) + cb * 16 + col) & (RING_PTS - 1)) * 4, LDS_RING_T, pt.t);
@@ -518,7 +550,7 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
                 lds_store<u32x4>(c.b_posx, cb * 2048 + e * 1024, r);
             }
         }
-        {   // posd: 8 slots per lane group (nerf_layout::posd_col_f32)
+        if constexpr (!RAY_POSD) {   // posd: 8 slots per lane group (nerf_layout::posd_col_f32)
             const float dd[3] = {pt.d1, pt.d2, pt.d3};
             float v[8];
 #pragma unroll

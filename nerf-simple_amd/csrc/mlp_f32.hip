@@ -71,6 +71,7 @@ struct Ctx {
     __amdgpu_buffer_rsrc_t wrsrc;
     unsigned wave_goff, lane16;
     unsigned b_wread, b_wstore, b_bias, b_posx, b_posd;
+    unsigned posd_addr, posd_stride;   // this tile's direction fragment of the lane and the byte step between its two halves (stage_inputs)
     int wave, lane;
 };
 
@@ -153,7 +154,8 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, const float (&in)[64], 
             const int qq = q < Q_CHAIN ? q : 0;
             bq[0] = in[4 * qq + 0]; bq[1] = in[4 * qq + 1]; bq[2] = in[4 * qq + 2]; bq[3] = in[4 * qq + 3];
         } else {
-            bq = lds_load<f32x4>(D.extra_kind == 1 ? c.b_posx : c.b_posd, (q - Q_CHAIN) * 1024);
+            bq = D.extra_kind == 1 ? lds_load<f32x4>(c.b_posx, (q - Q_CHAIN) * 1024)
+                                   : lds_load<f32x4>(c.posd_addr + (q - Q_CHAIN) * c.posd_stride, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         // two accumulation chains (dependent-issue latency 40 > issue 32 cycles)
@@ -197,15 +199,40 @@ __device__ __forceinline__ float enc_exact(float x, int idx) {
 // p_end: one past the last valid point (a.P, or the end of the workgroup's ray range in the fused render);
 // ring_q0 >= 0: also drop the sample position into the ring slot of this point
 template <bool RAYS>
-__device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base, long long p_end,
+__device__ __forceinline__ void stage_inputs(Ctx& c, const MlpArgs& a, long long tile_base, long long p_end,
                                              int ring_q0) {
     const int col = c.lane & 15, g = c.lane >> 4;
     long long p = tile_base + c.wave * 16 + col;
     const bool valid = p < p_end;
     if (!valid) p = p_end - 1;
     PointIn pt;
+    c.posd_addr = c.b_posd;
+    c.posd_stride = 1024;
     if constexpr (RAYS) {
-        pt = fetch_point_rays(a, p);
+        // Direction features once per RAY of the tile instead of once per sample (mlp_bf16_16.hip stage_inputs has the
+        // reasoning): here each of them is an exact sincosf, a quarter of the tile's encoding work.  One LDS slot of
+        // 128 B per ray, laid out [half q][lane group g][16 B]; value (g, slot s) by thread 32 * ray + 8 g + s.
+        const long long b0 = tile_base / a.N;
+        const long long last = (tile_base + TILE_PTS < p_end ? tile_base + TILE_PTS : p_end) - 1;
+        const int nrays = (int)(last / a.N - b0) + 1;
+        for (int idx = threadIdx.x; idx < nrays * 32; idx += WAVES * 64) {
+            const int ray = idx >> 5, slot = idx & 31, gg = slot >> 3, sl = slot & 7;
+            const float* rp = a.rays + (b0 + ray) * 6 + 3;
+            const float dx = rp[0], dy = rp[1], dz = rp[2];
+            const float nrm = norm3(dx, dy, dz);
+            float val = 0.f;
+            if (sl < 6) {
+                const int cd = sl >> 1;
+                val = enc_exact(__fdiv_rn(cd == 0 ? dx : cd == 1 ? dy : dz, nrm), 2 * gg + (sl & 1));
+            } else if (sl == 6 && gg < 3) {
+                val = __fdiv_rn(gg == 0 ? dx : gg == 1 ? dy : dz, nrm);
+            }
+            lds_store<float>(LDS_POSD + ray * 128 + (sl >> 2) * 64 + gg * 16 + (sl & 3) * 4, 0, val);
+        }
+        const RaySample rs = split_point(p, a.N);
+        c.posd_addr = LDS_POSD + (unsigned)(rs.b - b0) * 128 + g * 16;
+        c.posd_stride = 64;
+        pt = fetch_point_rays<false>(a, p, rs);
         if (valid && g == 0 && a.ts_out) a.ts_out[p] = pt.t;
         if (ring_q0 >= 0 && valid && g == 0)
             lds_store<float>(((unsigned)(ring_q0 + c.wave * 16 + col) & (RING_PTS - 1)) * 4, LDS_RING_T, pt.t);
@@ -225,8 +252,8 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
             lds_store<f32x4>(c.b_posx, q * 1024, r);
         }
     }
-    // posd: 8 slots per lane group (nerf_layout::posd_col_f32)
-    {
+    // posd: 8 slots per lane group (nerf_layout::posd_col_f32) -- per sample only when the directions are (points mode)
+    if constexpr (!RAYS) {
         const float dd[3] = {pt.d1, pt.d2, pt.d3};
         float v[8];
 #pragma unroll

@@ -188,6 +188,8 @@ __device__ __forceinline__ float device_rng_uniform(const MlpArgs& a, RaySample 
 }
 
 // u_pre: the point's device-RNG draw when the caller already has it (have_u), see mlp_bf16_16.hip stage_inputs
+// DIR = false: the unit direction is left out (d1..d3 = 0) for callers that encode it once per ray instead
+template <bool DIR = true>
 __device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long p, RaySample rs, float u_pre = 0.f,
                                                     bool have_u = false) {
     PointIn r;
@@ -213,11 +215,15 @@ __device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long 
     r.x = __fadd_rn(ox, __fmul_rn(dx, t));
     r.y = __fadd_rn(oy, __fmul_rn(dy, t));
     r.z = __fadd_rn(oz, __fmul_rn(dz, t));
-    // torch.norm over 3 elements on CPU == sqrt(fma(z,z,fma(y,y,x*x))) bit for bit
-    const float nrm = norm3(dx, dy, dz);
-    r.d1 = __fdiv_rn(dx, nrm);
-    r.d2 = __fdiv_rn(dy, nrm);
-    r.d3 = __fdiv_rn(dz, nrm);
+    if constexpr (DIR) {
+        // torch.norm over 3 elements on CPU == sqrt(fma(z,z,fma(y,y,x*x))) bit for bit
+        const float nrm = norm3(dx, dy, dz);
+        r.d1 = __fdiv_rn(dx, nrm);
+        r.d2 = __fdiv_rn(dy, nrm);
+        r.d3 = __fdiv_rn(dz, nrm);
+    } else {
+        r.d1 = r.d2 = r.d3 = 0.f;
+    }
     return r;
 }
 
