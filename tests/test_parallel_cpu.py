@@ -78,6 +78,18 @@ def _worker(rank, world, port, job, tmp):
             # the flat-vector form GraphedTrainStep calls between its two graphs
             x = torch.full((7,), float(rank + 1))
             assert parallel.allreduce_flat_(x) is x and bool((x == sum(range(1, world + 1)) / world).all())
+            # the bucketed, overlapped form GraphedTrainStep uses with more than one replica: two buckets of ONE flat
+            # vector, each started asynchronously (work runs beside whatever the caller does next), both awaited
+            # before the optimizer; the buckets are views, so the flat vector ends up reduced in place
+            flat2 = torch.arange(12, dtype=torch.float32) * (rank + 1)
+            late, head = flat2[5:], flat2[:5]
+            h1 = parallel.allreduce_start_(late)
+            busy = torch.ones(1000).sum()                         # "the head-gradient launch"
+            h2 = parallel.allreduce_start_(head)
+            parallel.allreduce_wait_(h1)
+            parallel.allreduce_wait_(h2)
+            assert float(busy) == 1000.0
+            assert torch.equal(flat2, torch.arange(12, dtype=torch.float32) * (sum(range(1, world + 1)) / world))
             # ragged pixel shards gathered into a caller-provided table
             n_tot = 5
             lo, hi = parallel.shard_range(n_tot, rank, world)
