@@ -209,6 +209,7 @@ def init_rank(args):
         backend = os.environ.get("NERF_BENCH_BACKEND", "nccl")
         if os.environ.get("NERF_BENCH_SHARE_GPU") == "1":
             local_rank = 0
+        local_rank %= max(torch.cuda.device_count(), 1)       # a launcher may have narrowed this rank's visible devices
         torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -254,10 +255,13 @@ def ranks_seen(dist, dev, world):
     t = torch.tensor([float(dist.get_rank() + 1)], device=dev)
     dist.all_reduce(t)
     props = torch.cuda.get_device_properties(dev)
-    ident = (socket.gethostname(), str(getattr(props, "uuid", "")) or str(getattr(props, "pci_bus_id", dev.index)), dev.index)
+    ident = (socket.gethostname(), str(getattr(props, "uuid", "")), dev.index)
     idents = [None] * world
     dist.all_gather_object(idents, ident)
-    distinct = len({(h, u) for h, u, _ in idents}) == world
+    # one device per rank: distinct (host, visible index) pairs, or -- when a launcher narrows each rank's visibility to
+    # one GPU, so every rank sees index 0 -- distinct device UUIDs; only a collision in BOTH says ranks share a card
+    distinct = (len({(h, i) for h, _, i in idents}) == world or
+                (all(u for _, u, _ in idents) and len({(h, u) for h, u, _ in idents}) == world))
     seen = {"world_size": dist.get_world_size(), "rank_sum_check": float(t.item()) == world * (world + 1) / 2,
             "backend": dist.get_backend(), "devices_distinct": distinct, "device_index_per_rank": [i for _, _, i in idents]}
     if not seen["rank_sum_check"] or seen["world_size"] != world:
