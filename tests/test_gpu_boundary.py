@@ -228,3 +228,44 @@ def test_foreign_net_path_is_the_same_arithmetic(dev, golden, synthetic):
     rgb.sum().backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in tiny.parameters())
     assert float(tiny[0].weight.grad.abs().max()) > 0
+
+
+TOL_ODD = {"fp32": 1e-4, "fp16": 7e-3, "bf16": 4.5e-2}       # the (precision, structured) tolerances of tests/test_gpu_parity.py
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fp16", "bf16"])
+def test_render_ragged_shapes_vs_oracle(dev, oracle, synthetic, precision):
+    """render_nerf against the oracle (not against another kernel path) at shapes nothing else is sized like: a single
+    ray, two samples, rays that straddle tiles (N = 65, 300), the longest ray of the one-launch path (768), the first
+    one of the two-launch path (769), near and far planes other than the defaults -- all five outputs -- and the empty
+    batch."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import render_nerf
+    sd = synthetic.synthetic_state_dict(0, "structured")
+    net = Nerf(precision=precision).to(dev)
+    net.load_state_dict(sd)
+    table = scene_rays(oracle, synthetic, 32)
+    tol = TOL_ODD[precision]
+    gen = torch.Generator().manual_seed(77)
+    for B, N, tn, tf in ((1, 2, 2, 6), (3, 5, 2, 6), (37, 65, 2, 6), (5, 300, 2, 6), (2, 768, 2, 6), (3, 769, 2, 6),
+                         (1000, 31, 2, 6), (64, 64, 0.5, 9.5)):
+        rays = table[torch.randperm(table.shape[0], generator=gen)[:B]].contiguous()
+        u = torch.rand(B, N, generator=gen)
+        with torch.no_grad():
+            want = oracle.render_nerf(rays, sd, N, tn, tf, u=u)
+            got = render_nerf(rays.to(dev), net, N, tn, tf, u=u.to(dev))
+        for name, a, b in zip(("rgb", "disp", "alpha", "acc", "w"), got, want):
+            assert a.shape == b.shape, (B, N, name)
+            a, b = a.cpu().numpy(), b.numpy()
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (B, N, name)
+            ok = ~np.isnan(b)
+            err = np.abs(a[ok] - b[ok]).max() / max(1.0, np.abs(b[ok]).max()) if ok.any() else 0.0
+            assert err <= tol, (precision, B, N, tn, tf, name, err)
+    # B = 0: the reference returns empty tensors of the right shapes (every op of utils/rendering.py:13-85 accepts
+    # an empty batch) and still "draws" torch.rand(0, N): nothing
+    empty = torch.empty(0, 6)
+    with torch.no_grad():
+        want = oracle.render_nerf(empty, sd, 8)
+        got = render_nerf(empty.to(dev), net, 8)
+    for a, b in zip(got, want):
+        assert tuple(a.shape) == tuple(b.shape)

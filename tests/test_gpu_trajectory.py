@@ -277,3 +277,47 @@ def test_inference_after_graphed_steps_sees_new_weights(dev, golden, oracle, syn
             got, want = render_nerf(rays, net, N, u=u, precision=p)[0], render_nerf(rays, fresh, N, u=u, precision=p)[0]
             assert torch.equal(got, want), p
             assert float((got - before[p]).abs().max()) > 1e-3, p      # and the weights did move
+
+
+def test_reference_loop_body_verbatim(dev, golden, oracle, synthetic):
+    """The drop-in claim, literally: the statements of the reference's training loop (train.py:41-57) with only the
+    import root swapped -- ``Nerf().cuda()``, ``nn.MSELoss()``, ``torch.optim.Adam(net.parameters(), lr=5e-4)``,
+    ``render_nerf(rays.cuda(), net, params['Nf'])``, ``loss.backward()``, ``optimizer.step()``, the param_groups decay
+    loop -- run for the first ten iterations of G8 and give its losses (torch's Adam and MSELoss on the HIP path's
+    gradients; same band as the trajectory test)."""
+    import torch.nn as nn
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import render_nerf
+    g = golden("trajectory.npz")
+    rays_tab, gt_tab = dataset_tables(golden, oracle, synthetic)
+    params = {"Nf": int(g["N"]), "batch_size": int(g["B"]), "lr_init": float(g["lr_init"]), "lr_final": float(g["lr_final"]),
+              "num_iters": int(g["K"])}
+    seed = int(g["seeds"][0])
+    saved = torch.get_rng_state()
+    try:
+        decay = np.exp(np.log(params["lr_final"] / params["lr_init"]) / params["num_iters"])
+        net = Nerf(precision="bf16").cuda()
+        net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+        criterion = nn.MSELoss()
+        optimizer = torch.optim.Adam(net.parameters(), lr=5e-4)
+        losses = []
+        torch.manual_seed(seed)
+        for i in range(10):
+            ray_ids = torch.randperm(rays_tab.size(0))[:params["batch_size"]]            # rg.select(mode='train', N=batch_size)
+            rays = rays_tab[ray_ids, :]
+            gt_colors = gt_tab[ray_ids, :].float().cuda()
+            optimizer.zero_grad()
+            rgb, depth, alpha, acc, w = render_nerf(rays.cuda(), net, params["Nf"])
+            loss = criterion(rgb, gt_colors)
+            loss.backward()
+            optimizer.step()
+            for p in optimizer.param_groups:
+                p["lr"] = p["lr"] * decay
+            losses.append(loss.item())
+    finally:
+        torch.set_rng_state(saved)
+    ref = g[f"loss/{seed}"][:10]
+    rl = np.abs(np.asarray(losses) - ref) / ref
+    print("reference loop body verbatim, 10 iterations: loss deviation", rl)
+    assert rl.max() <= 1.3e-2, rl
+    assert alpha.shape == (params["batch_size"], params["Nf"]) and depth.shape == (params["batch_size"],)
