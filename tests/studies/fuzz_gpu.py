@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised shape sweeps on the GPU box, beyond what the test suite runs every round.
 
-    python tools/fuzz_gpu.py render     # 340 random (B, N <= 768, jitter mode) cases, three precisions:
+    python tests/studies/fuzz_gpu.py render     # 340 random (B, N <= 768, jitter mode) cases, three precisions:
                                         # the fused render kernel == MLP launch + compositor launch, bit for bit
-    python tools/fuzz_gpu.py train      # 25 ragged (B, N) batches: fused training gradients vs the CPU oracle's
+    python tests/studies/fuzz_gpu.py train      # 25 ragged (B, N) batches: fused training gradients vs the CPU oracle's
                                         # fp32 autograd under the test suite's stated bounds (tests/test_gpu_training.py)
 
 Uses oracle/ as the checker, like the tests.  Batches of a few points can exceed the per-tensor bound on the two sigma
@@ -14,7 +14,7 @@ of 1e-3 is then tens of per cent of it (2 x 3 points: 15 % of sum |d sigma_i|); 
 import sys
 import os
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def render():
