@@ -195,13 +195,35 @@ def pmc_traffic(kernel, mode, precision=None):
     return None, None
 
 
+_JSON_OUT = None
+
+
+def emit(res):
+    """The one JSON line, on the process's original stdout."""
+    out = _JSON_OUT or sys.stdout
+    print(json.dumps(res), file=out, flush=True)
+
+
 def init_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     backend = None
-    if world > 1:
+    # NERF_BENCH_FORCE_DIST=1 with one rank: the process group is created anyway and every collective of the multi-GPU
+    # step is issued (parallel.force_collectives) -- the RCCL call pattern rehearsed on a single MI355X
+    forced = world == 1 and os.environ.get("NERF_BENCH_FORCE_DIST") == "1"
+    if forced:
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+    if world > 1 or forced:
+        # RCCL prints a version banner on stdout when its first communicator comes up; the contract is ONE JSON line
+        # there.  From here on file descriptor 1 is stderr for everything but emit().
+        global _JSON_OUT
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # rehearsal knobs (1-GPU box): NERF_BENCH_BACKEND=gloo NERF_BENCH_SHARE_GPU=1 lets several
@@ -217,12 +239,15 @@ def init_rank(args):
             dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    return world, rank, dev, dist, backend
+    if forced:
+        from nerf_simple_amd import parallel
+        parallel.force_collectives(True)
+    return world, rank, dev, (dist if (world > 1 or forced) else None), backend
 
 
 def timed_loop(step, args, dist, dev, world):
     def fence():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -238,7 +263,7 @@ def timed_loop(step, args, dist, dev, world):
     fence()
     elapsed = time.perf_counter() - t0
     gc.enable()
-    if world > 1:
+    if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -250,7 +275,7 @@ def ranks_seen(dist, dev, world):
     of letting a mis-launched job print a number: the backend is nccl (= RCCL on ROCm) unless the rehearsal knob
     NERF_BENCH_BACKEND says otherwise, every rank sits on its own device unless NERF_BENCH_SHARE_GPU=1, and an
     all-reduce of (rank + 1) over the group gives world (world + 1) / 2."""
-    if world == 1:
+    if dist is None:
         return {"world_size": 1, "rank_sum_check": True}
     t = torch.tensor([float(dist.get_rank() + 1)], device=dev)
     dist.all_reduce(t)
@@ -275,7 +300,7 @@ def ranks_seen(dist, dev, world):
 
 def gather_floats(dist, dev, world, value):
     """One float per rank -> list on every rank."""
-    if world == 1:
+    if dist is None:
         return [float(value)]
     t = torch.zeros(world, dtype=torch.float64, device=dev)
     t[dist.get_rank()] = float(value)
@@ -404,6 +429,7 @@ def aux_configs(dev, sd, rays_800):
 
 def run_render(args):
     world, rank, dev, dist, backend = init_rank(args)
+    multi = dist is not None                 # collectives are issued: more than one rank, or the single-rank rehearsal
     from nerf_simple_amd import _lib, parallel
     from nerf_simple_amd.utils import synthetic
     from nerf_simple_amd.utils.nets import Nerf
@@ -427,20 +453,20 @@ def run_render(args):
     nws = int(lib.nerf_amd_render_workspace_bytes(code, nr, N_SAMPLES))       # 0 for the fused render
     ws = torch.empty(nws, dtype=torch.uint8, device=dev) if nws else None
     shard = torch.empty((nr, 4), dtype=torch.float32, device=dev)
-    image = torch.empty((n_rays, 4), dtype=torch.float32, device=dev) if world > 1 else shard
+    image = torch.empty((n_rays, 4), dtype=torch.float32, device=dev) if multi else shard
     events = []
 
     def step(record):
         st = _lib.stream_ptr(dev)
         if record:
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 if world > 1 else 2)]
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 if multi else 2)]
             ev[0].record()
         _lib.check(lib.nerf_amd_render_pixels_forward(
             _lib.ptr(rays), None, _lib.ptr(tbins), _lib.ptr(packed), code, _lib.FLAG_DEVICE_RNG, 1234, lo,
             _lib.ptr(shard), _lib.ptr(ws), nr, N_SAMPLES, st), "nerf_amd_render_pixels_forward")
         if record:
             ev[1].record()
-        if world > 1:
+        if multi:
             parallel.gather_pixels(shard, n_rays, out=image)     # ONE RCCL all-gather per image
             if record:
                 ev[2].record()
@@ -450,7 +476,7 @@ def run_render(args):
     elapsed = timed_loop(step, args, dist, dev, world)
     seen = ranks_seen(dist, dev, world)
     kern_ms = sum(e[0].elapsed_time(e[1]) for e in events) / max(len(events), 1)
-    coll_ms = sum(e[1].elapsed_time(e[2]) for e in events) / max(len(events), 1) if world > 1 else 0.0
+    coll_ms = sum(e[1].elapsed_time(e[2]) for e in events) / max(len(events), 1) if multi else 0.0
     kern_ms_ranks = gather_floats(dist, dev, world, kern_ms)
     coll_ms_ranks = gather_floats(dist, dev, world, coll_ms)
     from nerf_simple_amd.utils.nets import packed_status
@@ -464,7 +490,7 @@ def run_render(args):
         launch_samples = nr * N_SAMPLES
         achieved = launch_samples * FLOP_PER_SAMPLE / (kern_ms * 1e-3) / 1e12
         kern = RENDER_KERNEL[args.precision]
-        traffic, traffic_src = pmc_traffic(kern, "render", args.precision) if world == 1 else (None, None)
+        traffic, traffic_src = pmc_traffic(kern, "render", args.precision) if not multi else (None, None)
         res = {
             "metric": "ray-samples/sec at 800x800x128", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -479,13 +505,13 @@ def run_render(args):
                                             "meets the 0.05 dB PSNR target on these weights: DESIGN.md section 2; bf16 is timed "
                                             "in aux.bf16 and misses that target: known gap)",
                                     "bf16": "bf16 MFMA operands, fp32 accumulate", "fp32": "exact-f32 MFMA"}[args.precision],
-                       "parallelism": f"rays sharded x{world}" + (" + all_gather of [rgb,disp]" if world > 1 else "")},
+                       "parallelism": f"rays sharded x{world}" + (" + all_gather of [rgb,disp]" if multi else "")},
             "ranks": seen,
             "kernel_ms_per_rank": kern_ms_ranks,
-            "collective_ms": max(coll_ms_ranks) if world > 1 else 0.0,
-            "collective_ms_per_rank": coll_ms_ranks if world > 1 else [],
+            "collective_ms": max(coll_ms_ranks) if multi else 0.0,
+            "collective_ms_per_rank": coll_ms_ranks if multi else [],
             "collective": "all_gather_into_tensor of the packed [rgb, disparity] pixels, events on the launch stream "
-                          "from the end of the render kernel to the end of the gather" if world > 1 else None,
+                          "from the end of the render kernel to the end of the gather" if multi else None,
             "roofline": {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak / 1e12,
                          "unit": "TFLOP/s", "frac": achieved * 1e12 / peak, "traffic": traffic,
                          "traffic_source": traffic_src,
@@ -495,9 +521,9 @@ def run_render(args):
                          "kernel_ms": kern_ms, "flop_per_sample": FLOP_PER_SAMPLE,
                          "samples_per_launch": launch_samples},
         }
-        if world == 1 and not args.no_aux:
+        if not multi and not args.no_aux:
             res["aux"] = aux_configs(dev, sd, rays)
-        if world == 1 and not args.no_cpu_baseline:
+        if not multi and not args.no_cpu_baseline:
             base, (crays, cu, cout, O) = cpu_baseline(sd, rays_cpu, args.cpu_rays)
             with torch.no_grad():
                 g = render_nerf(crays.to(dev), net, N_SAMPLES, u=cu.to(dev))
@@ -522,8 +548,8 @@ def run_render(args):
                                            "note": "bf16's 8-bit weight mantissa shifts the image systematically on these "
                                                    "high-gain weights (DESIGN.md section 2): the 0.05 dB criterion is a known "
                                                    "gap of the bf16 operand mode, which is why fp16 operands are the default"})
-        print(json.dumps(res), flush=True)
-    if world > 1:
+        emit(res)
+    if multi:
         dist.destroy_process_group()
 
 
@@ -532,6 +558,7 @@ def run_render(args):
 # ----------------------------------------------------------------------------------------------
 def run_train(args):
     world, rank, dev, dist, backend = init_rank(args)
+    multi = dist is not None
     from nerf_simple_amd import _lib, parallel
     from nerf_simple_amd.optim import FusedAdam
     from nerf_simple_amd.training import GraphedTrainStep, lr_decay_factor
@@ -545,7 +572,8 @@ def run_train(args):
     net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
     parallel.broadcast_parameters(net)
     opt = FusedAdam(net, lr=5e-4)
-    stepper = GraphedTrainStep(net, opt, B, N, group=(dist.group.WORLD if world > 1 else None), timing=world > 1)
+    stepper = GraphedTrainStep(net, opt, B, N, group=(dist.group.WORLD if multi else None), timing=multi,
+                               buckets=int(os.environ.get("NERF_BENCH_BUCKETS", "1")))
     # synthetic batch: 4096 rays of a 64x64 camera on this rank's own azimuth, random targets, four
     # pre-drawn jitter tables cycled through (the reference's per-step host work is out of the timed path)
     pose = torch.from_numpy(spherical_to_pose(4, -30, 20.0 * rank)).float()
@@ -556,12 +584,17 @@ def run_train(args):
     decay = lr_decay_factor(5e-4, 5e-5, 10000)              # reference configs/lego.yaml lr_init / lr_final shape
     it = [0]
 
+    timed = [False]
+
     def step(record):
+        if record and not timed[0]:
+            timed[0] = True
+            stepper.reset_timing()                  # the exchange times are of the timed steps only
         stepper.step(rays, gt, u=us[it[0] & 3], decay=decay)
         it[0] += 1
 
     elapsed = timed_loop(step, args, dist, dev, world)
-    coll = stepper.collective_times() if world > 1 else None      # (span, exposed) ms per step, warm-up included
+    coll = stepper.collective_times() if multi else None      # (span, exposed) ms per timed step
     seen = ranks_seen(dist, dev, world)
     loss = float(stepper.loss)
     # duration of the dominant kernel (dW + db, nerf_amd_param_gradients): 20 more launches on the same
@@ -586,7 +619,7 @@ def run_train(args):
         ms = elapsed / args.steps * 1e3
         value = world * P * args.steps / elapsed
         achieved = DW_BYTES_PER_POINT * P / (dw_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic("dw_gemm_kernel(", "train") if world == 1 else (None, None)
+        traffic, traffic_src = pmc_traffic("dw_gemm_kernel(", "train") if not multi else (None, None)
         res = {
             "metric": "training ray-samples/sec (forward + backward + Adam) at 4096 rays x 64 samples per GPU",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -595,15 +628,17 @@ def run_train(args):
             "config": {"workload": "train.py step: 4096 rays x 64 samples per GPU, bf16, FusedAdam, hipGraph replay "
                                    "(BASELINE config 5)",
                        "rays_per_gpu": B, "samples_per_ray": N, "global_batch_rays": B * world,
-                       "parallelism": f"data-parallel x{world}" + (" + all_reduce of the flat 2.38 MB gradient" if world > 1 else "")},
+                       "parallelism": f"data-parallel x{world}" + (" + all_reduce of the flat 2.38 MB gradient" if multi else "")},
             "ranks": seen, "final_loss": loss,
             "kernel_ms_per_rank": dw_ms_ranks,
-            "collective_ms": max(span_ranks) if world > 1 else 0.0,
-            "collective_exposed_ms": max(exposed_ranks) if world > 1 else 0.0,
-            "collective_ms_per_rank": span_ranks if world > 1 else [],
-            "collective": "two all-reduces of the flat gradient (1.27 MB, then 1.12 MB); collective_ms = from the end of the "
-                          "late-layer gradient launch to both reduced, collective_exposed_ms = the part behind the end of the "
-                          "head-gradient launch that runs beside the first exchange" if world > 1 else None,
+            "collective_ms": max(span_ranks) if multi else 0.0,
+            "collective_exposed_ms": max(exposed_ranks) if multi else 0.0,
+            "collective_ms_per_rank": span_ranks if multi else [],
+            "collective": ("one all-reduce of the flat 2.38 MB gradient between the two graphs of the step (events on the "
+                           "launch stream); fully exposed" if not stepper.bucketed else
+                           "two all-reduces of the flat gradient (1.27 MB, then 1.12 MB); collective_ms = from the end of the "
+                           "late-layer gradient launch to both reduced, collective_exposed_ms = the part behind the end of the "
+                           "head-gradient launch that runs beside the first exchange") if multi else None,
             "roofline": {"bound": "hbm", "kernel": "dw_gemm_kernel (timed: nerf_amd_param_gradients = zero fill + d_raw pack + dw_gemm)",
                          "achieved": achieved, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / PEAK_HBM,
                          "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": dw_ms,
@@ -611,8 +646,8 @@ def run_train(args):
                          "kernel_ms_note": "median of 20 extra launches on the step's own buffers after the timed region",
                          "step_mfma_frac": 3 * FLOP_PER_SAMPLE * P / (ms * 1e-3) / PEAK_BF16},
         }
-        print(json.dumps(res), flush=True)
-    if world > 1:
+        emit(res)
+    if multi:
         dist.destroy_process_group()
 
 

@@ -23,6 +23,25 @@ def world_info(group=None):
     return 0, 1
 
 
+_single_rank_collectives = False
+
+
+def force_collectives(on=True):
+    """Rehearsal switch: with a process group of ONE rank the collectives below are normally skipped; switched on,
+    they are issued all the same, so the exact call pattern of a multi-GPU job -- RCCL all-gather / all-reduce on the
+    launch stream, the asynchronous bucketed exchange -- runs on a single MI355X (tests/test_gpu_multirank.py,
+    `NERF_BENCH_FORCE_DIST=1 python bench.py`)."""
+    global _single_rank_collectives
+    _single_rank_collectives = bool(on)
+
+
+def collectives_active(group=None):
+    """True when an exchange has to be issued: more than one replica, or the single-rank rehearsal."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or _single_rank_collectives
+
+
 def shard_range(n, rank, world):
     """Contiguous, balanced range of rank ``rank``: [lo, hi)."""
     return rank * n // world, (rank + 1) * n // world
@@ -34,7 +53,7 @@ def gather_pixels(shard, n_total, group=None, out=None):
     Equal shards use one all_gather_into_tensor; ragged ones are padded to the
     largest shard so it is still a single collective."""
     rank, world = world_info(group)
-    if world == 1:
+    if not collectives_active(group):
         return shard if out is None else out.copy_(shard)
     C = shard.shape[1]
     if out is None:
@@ -97,7 +116,7 @@ def allreduce_flat_(flat, group=None):
     """In-place mean over the data-parallel replicas of ONE flat gradient vector (the fused
     backward's 2.38 MB bucket): a single all-reduce, then a scale."""
     rank, world = world_info(group)
-    if world > 1:
+    if collectives_active(group):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         flat /= world
     return flat
@@ -108,7 +127,7 @@ def allreduce_start_(t, group=None):
     collective waits for what is queued on the current stream NOW and runs on the backend's own stream, so kernels
     launched afterwards overlap it.  Returns a handle for allreduce_wait_ (None with a single replica)."""
     rank, world = world_info(group)
-    if world == 1:
+    if not collectives_active(group):
         return None
     avg = dist.get_backend(group) == "nccl"                 # RCCL reduces to the mean itself; gloo has no AVG
     work = dist.all_reduce(t, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group, async_op=True)
@@ -133,7 +152,7 @@ def allreduce_gradients(params, group=None):
     gradient of the global-batch MSE (reference train.py:52-54)."""
     rank, world = world_info(group)
     params = [p for p in params if p.grad is not None]
-    if world == 1 or not params:
+    if not collectives_active(group) or not params:
         return
     flat = flat_grad_view(params)
     if flat is not None:                       # the fused backward's flat vector: reduce it in place
@@ -152,7 +171,7 @@ def allreduce_gradients(params, group=None):
 def broadcast_parameters(module, src=0, group=None):
     """Make every replica start from rank ``src``'s weights (one flat broadcast)."""
     rank, world = world_info(group)
-    if world == 1:
+    if not collectives_active(group):
         return
     ps = list(module.parameters())
     flat = torch.cat([p.detach().reshape(-1) for p in ps])

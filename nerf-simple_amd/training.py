@@ -316,16 +316,22 @@ class GraphedTrainStep:
                  (9 kernel nodes, all through the C ABI: no torch kernels, no memset node)
         graph B: Adam over the flat parameter vector -> re-pack the two MFMA weight images (one kernel)
 
-    With a process group of more than one replica the parameter gradients are produced in two launches and the
-    flat vector is reduced in two buckets (include/nerf_amd.h nerf_amd_grad_bucket_range):
+    With a process group of more than one replica the flat gradient vector is averaged between graph A and graph B:
 
-        graph A1: ... -> dX chain -> gradients of the LATE layers (skip_conn_layer ... color_fc.2: the tail of the vector)
-        all-reduce of that bucket (1.27 MB) starts on the collective's own stream
-        graph A2: gradients of layers_0.* (the head of the vector)        <- runs while bucket 1 is on the wire
-        all-reduce of the head bucket (1.12 MB); both are awaited; graph B
+        buckets=1 (default)  ONE in-place all-reduce of the 2.38 MB vector; fully exposed, and the cheapest form
+                             measured: +16 ... 26 us per step with RCCL on one rank (1.185 -> 1.201 ms).
+        buckets=2            the gradients are produced in two launches and reduced in two buckets
+                             (include/nerf_amd.h nerf_amd_grad_bucket_range):
+                               graph A1: ... -> dX chain -> gradients of the LATE layers (the tail of the vector)
+                               all-reduce of that bucket (1.27 MB) starts on the collective's own stream
+                               graph A2: gradients of layers_0.* (the head)      <- runs while bucket 1 is on the wire
+                               all-reduce of the head bucket (1.12 MB); both awaited; graph B
+                             Only the second exchange is exposed -- but the split itself costs 75 ... 90 us per step (a
+                             second 64 MB tail of split-K atomics and a second ramp of the HBM-bound gradient kernel),
+                             measured with RCCL on one rank: 1.288 vs 1.201 ms.  It pays only where one 1.27 MB
+                             all-reduce takes longer than that.
 
-    so only the second, smaller exchange is exposed.  ``timing=True`` records events around the exchange
-    (``collective_times()``).
+    ``timing=True`` records events around the exchange (``collective_times()``).
 
     Step-dependent scalars do not live in kernel arguments: the jitter comes from the ``u``
     buffer (filled per call; default the reference's one ``torch.rand(B, N)`` draw from the CPU
@@ -336,7 +342,7 @@ class GraphedTrainStep:
     ``step(rays, gt, u=None, decay=1.0)`` returns the loss as a 0-d device tensor (no sync).
     """
 
-    def __init__(self, net, optimizer, n_rays, N, *, tn=2, tf=6, group=None, timing=False):
+    def __init__(self, net, optimizer, n_rays, N, *, tn=2, tf=6, group=None, timing=False, buckets=1):
         from . import parallel
         from .optim import FusedAdam
         from .utils.rendering import _tbins
@@ -346,7 +352,10 @@ class GraphedTrainStep:
             raise RuntimeError("the optimizer belongs to another module")
         _check_trainable(net.precision)
         self.net, self.opt, self.group = net, optimizer, group
-        self.bucketed = group is not None and parallel.world_info(group)[1] > 1
+        if buckets not in (1, 2):
+            raise ValueError("buckets must be 1 (one all-reduce between the two graphs, the default) or 2 (overlapped)")
+        self.exchange = group is not None and parallel.collectives_active(group)
+        self.bucketed = self.exchange and buckets == 2
         self.timing, self._events = bool(timing), []
         self.B, self.N = int(n_rays), int(N)
         dev = optimizer.flat.device
@@ -501,6 +510,15 @@ class GraphedTrainStep:
             if ev:
                 ev[2].record()
                 self._events.append(ev)
+        elif self.exchange:
+            # buckets=1: the whole 2.38 MB vector in one all-reduce between the two graphs, fully exposed
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if self.timing else None
+            if ev:
+                ev[0].record()
+            parallel.allreduce_flat_(self.grads, group=self.group)
+            if ev:
+                ev[1].record()
+                self._events.append([ev[0], ev[0], ev[1]])
         self.graph_b.replay()
         # graph B re-packed the two training images; any other image of the module (fp16 / fp32 inference) is now
         # stale -- and the kernels wrote through the flat buffer, so the parameters' versions did not move
@@ -511,6 +529,10 @@ class GraphedTrainStep:
         return self.loss
 
     __call__ = step
+
+    def reset_timing(self):
+        """Forget the exchange events recorded so far (warm-up steps: the first collective creates the communicator)."""
+        self._events = []
 
     def collective_times(self):
         """(span_ms, exposed_ms) averaged over the steps recorded with timing=True: from the end of the late-layer

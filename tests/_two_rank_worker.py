@@ -47,7 +47,17 @@ def main():
     tnet.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
     parallel.broadcast_parameters(tnet)
     opt = FusedAdam(tnet, lr=5e-4)
-    stepper = GraphedTrainStep(tnet, opt, half, N, group=dist.group.WORLD, timing=True)
+    # the default exchange (one all-reduce between the graphs) on a twin module: its averaged gradient is the reference
+    # for the bucketed, overlapped form below
+    tnet1 = Nerf(precision="bf16").to(dev)
+    tnet1.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+    step1 = GraphedTrainStep(tnet1, FusedAdam(tnet1, lr=5e-4), half, N, group=dist.group.WORLD, timing=True)
+    assert step1.exchange and not step1.bucketed and step1.graph_a2 is None
+    step1.step(rays[sl].to(dev), gt[sl].to(dev), u=uu[sl].to(dev))
+    torch.cuda.synchronize()
+    res["grads_one_bucket"] = step1.grads.cpu().numpy()
+    assert step1.collective_times()[0] > 0
+    stepper = GraphedTrainStep(tnet, opt, half, N, group=dist.group.WORLD, timing=True, buckets=2)
     assert stepper.bucketed and stepper.graph_a2 is not None          # two gradient launches, two overlapped exchanges
     loss = stepper.step(rays[sl].to(dev), gt[sl].to(dev), u=uu[sl].to(dev))
     torch.cuda.synchronize()

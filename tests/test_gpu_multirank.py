@@ -92,8 +92,10 @@ def test_data_parallel_step_equals_global_batch(two_rank_results, golden, synthe
     assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max(), np.abs(got - want).max() / np.abs(want).max()
     assert abs(0.5 * (float(r0["loss"][0]) + float(r1["loss"][0])) - loss) <= 1e-5 * loss
     assert np.array_equal(r0["params"], r1["params"])
-    # the step reduces the gradient in two buckets, the first one beside the second gradient launch; three more
-    # replays leave both ranks with identical, finite parameters that moved
+    # one all-reduce between the graphs (the default) and the two-bucket, overlapped exchange average to the same
+    # gradient (summation order of the split-K atomics aside)
+    assert np.abs(r0["grads_one_bucket"] - got).max() <= 2e-5 * np.abs(want).max()
+    # the bucketed step: three more replays leave both ranks with identical, finite parameters that moved
     assert np.array_equal(r0["params4"], r1["params4"]) and np.isfinite(r0["params4"]).all()
     assert not np.array_equal(r0["params4"], r0["params"])
     print("2-rank gloo exchange: span / exposed ms", r0["collective_ms"])
@@ -117,3 +119,31 @@ def test_bench_self_launch_two_ranks(mode):
     assert res["scaling"] == ("strong" if mode == "render" else "weak")
     assert res["collective_ms"] > 0 and len(res["kernel_ms_per_rank"]) == 2
     assert res["ranks"]["backend"] == "gloo" and res["ranks"]["devices_distinct"] is False      # the rehearsal shares one GPU
+
+
+@pytest.mark.parametrize("mode", ["render", "train", "train2"])
+def test_bench_rccl_single_rank_rehearsal(mode):
+    """The multi-GPU step of bench.py over the REAL transport with the one GPU this box has: a process group of one rank
+    on backend nccl (= RCCL), every collective issued all the same (NERF_BENCH_FORCE_DIST=1 ->
+    parallel.force_collectives): init with device_id, the barrier / MAX all-reduce of the timed loop, the all-gather of
+    the pixels after every render, the two asynchronous AVG all-reduces of the gradient buckets beside the replayed
+    hipGraphs, all_gather_object in the self-check.  What it cannot show is the wire: more than one rank needs more than
+    one GPU."""
+    env = dict(os.environ, NERF_BENCH_FORCE_DIST="1", MASTER_PORT=str(free_port()),
+               NERF_BENCH_BUCKETS=("2" if mode == "train2" else "1"))
+    mode = "train" if mode == "train2" else mode
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NERF_BENCH_BACKEND", "NERF_BENCH_SHARE_GPU"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+                        "--mode", mode, "--no-cpu-baseline", "--no-aux"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 1 and res["ranks"]["backend"] == "nccl" and res["ranks"]["rank_sum_check"] is True
+    assert res["ranks"]["devices_distinct"] is True and res["collective_ms"] > 0 and len(res["kernel_ms_per_rank"]) == 1
+    if mode == "train":
+        assert res["collective_ms"] >= res["collective_exposed_ms"] >= 0 and np.isfinite(res["final_loss"])
+    print(f"RCCL single-rank rehearsal, {mode}: {res['ms_per_step']:.3f} ms/step, collective {res['collective_ms']:.4f} ms"
+          + (f" (exposed {res['collective_exposed_ms']:.4f})" if mode == "train" else ""))
