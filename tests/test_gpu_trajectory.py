@@ -321,3 +321,51 @@ def test_reference_loop_body_verbatim(dev, golden, oracle, synthetic):
     print("reference loop body verbatim, 10 iterations: loss deviation", rl)
     assert rl.max() <= 1.3e-2, rl
     assert alpha.shape == (params["batch_size"], params["Nf"]) and depth.shape == (params["batch_size"],)
+
+
+def test_psnr_criterion_on_trained_weights(dev, golden, oracle, synthetic):
+    """End to end on weights that come out of TRAINING rather than out of a generator: 1500 graphed steps (1024 rays x 64
+    samples, Adam 5e-4 -> 1e-4) on the two-view dataset of G8 -- whose target colours are the reference's render of the
+    teacher -- then a held-out third view (azimuth 20 degrees) rendered by the default fp16 kernel, by bf16 and by the
+    CPU oracle in fp32 from the trained state dict.  BASELINE's criterion |PSNR(GPU, T) - PSNR(CPU, T)| <= 0.05 dB
+    against the teacher's own fp32 render T of that view must hold for the default precision (bf16 is reported), and the
+    trained module must see its new weights in every precision (the graphed step updates them behind autograd's back)."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.optim import FusedAdam
+    from nerf_simple_amd.training import GraphedTrainStep, lr_decay_factor
+    from nerf_simple_amd.utils.rendering import render_nerf
+    rays_tab, gt_tab = dataset_tables(golden, oracle, synthetic)
+    rays_dev, gt_dev = rays_tab.to(dev), gt_tab.to(dev)
+    B, N, K = 1024, 64, 1500
+    net = Nerf().to(dev)                                     # default precision: fp16 inference, bf16 training kernels
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+    opt = FusedAdam(net, lr=5e-4)
+    stepper = GraphedTrainStep(net, opt, B, N)
+    decay = lr_decay_factor(5e-4, 1e-4, K)
+    gen = torch.Generator().manual_seed(5)
+    first = last = None
+    for i in range(K):
+        ids = torch.randperm(rays_tab.shape[0], generator=gen)[:B].to(dev)
+        u = torch.rand(B, N, generator=gen).to(dev)
+        loss = stepper.step(rays_dev[ids], gt_dev[ids], u=u, decay=decay)
+        if i == 0:
+            first = float(loss)
+    last = float(loss)
+    assert last < 0.05 * first, (first, last)               # it learned the scene (0.13 -> a few 1e-3)
+    sd_trained = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    hw = 64
+    pose = torch.from_numpy(oracle.spherical_to_pose(4, -30, 20.0)).float()
+    view = oracle.camera_rays(pose, [hw, hw, synthetic.focal_from_fov(hw)]).contiguous()
+    u = torch.rand(view.shape[0], 128, generator=gen)
+    with torch.no_grad():
+        T = torch.clip(oracle.render_nerf(view, synthetic.synthetic_state_dict(0, "structured"), 128, u=u)[0], 0, 1)
+        cpu = torch.clip(oracle.render_nerf(view, sd_trained, 128, u=u)[0], 0, 1)
+        p_cpu = float(oracle.img_psnr(T, cpu))
+        delta = {}
+        for prec in ("fp16", "bf16", "fp32"):
+            img = torch.clip(render_nerf(view.to(dev), net, 128, u=u.to(dev), precision=prec)[0], 0, 1).cpu()
+            delta[prec] = float(oracle.img_psnr(T, img)) - p_cpu
+    print(f"trained weights: loss {first:.4f} -> {last:.5f}; held-out view PSNR(CPU, teacher) {p_cpu:.2f} dB; "
+          f"delta fp16 {delta['fp16']:+.4f} dB, bf16 {delta['bf16']:+.4f} dB, fp32 {delta['fp32']:+.5f} dB")
+    assert p_cpu > 15.0                                       # a held-out view of a scene learned from two views in a second
+    assert abs(delta["fp32"]) <= 1e-3 and abs(delta["fp16"]) <= 0.05, delta
