@@ -3,6 +3,12 @@ training kernels (fused forward saving activations, compositor forward / backwar
 split-K GEMMs, Adam) against golden G6 (captured from the reference's own autograd) and against
 the CPU oracle's fp32 autograd on the same (rays, u, gt, weights).
 
+The REQUIREMENT on the training path -- gradients inside half the reference's own minibatch sampling deviation at the
+reference's real step shape, a 60-iteration trajectory inside fractions of the reference's own seed-to-seed spread --
+lives in tests/test_gpu_trajectory.py (fixtures G6b, G6c, G8).  The bounds in THIS file are
+regression guards fitted to the observed bf16 error (<= 3x observed) for shapes that have no fixture of their own:
+ragged batches, the structured weights, points mode.
+
 Stated bounds: per parameter tensor, relative L2 = ||g_gpu - g_ref|| / ||g_ref||.  The error is
 bf16 rounding of operands, saved activations and activation gradients through 12 layers; it is
 noise-like per point, so it averages down with the number of points P in the batch (observed on
