@@ -1,0 +1,83 @@
+"""The bench contract, checked on the committed lines (profiles/r03_bench.json, profiles/r03_train_bench.json): every
+field the driver reads is there, the numbers are consistent with each other, and bench.py's own helpers (argument
+parsing, PMC lookup by full kernel instantiation) behave -- no GPU needed."""
+import importlib.util
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline")
+
+
+def load(name):
+    return json.load(open(os.path.join(ROOT, "profiles", name)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    argv = sys.argv
+    sys.argv = ["bench.py"]
+    try:
+        spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.argv = argv
+    return mod
+
+
+def test_render_line():
+    d = load("r03_bench.json")
+    for k in REQUIRED + ("cpu_baseline", "aux"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "ray-samples/s" and d["data"] == "synthetic" and d["dtype"] in ("f16", "bf16", "f32")
+    assert "workload" in d["config"] and "model" not in d["config"]
+    samples = d["config"]["rays"] * d["config"]["samples_per_ray"]
+    assert samples == 800 * 800 * 128
+    assert abs(d["value"] - samples / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.001
+    assert abs(r["achieved"] - r["samples_per_launch"] * r["flop_per_sample"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_hbm_bytes"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] == "port" and c["cores"] >= 1 and abs(c["psnr_delta_vs_teacher_db"]) <= 0.05
+    aux = d["aux"]
+    assert set(aux) == {"bf16", "c2", "c4", "c5"} and set(aux["c5"]) == {"N64", "N128"}
+    for k in ("bf16", "c2", "c4"):
+        assert aux[k]["ms"] > 0 and 0 < aux[k]["frac_of_peak"] < 1 and aux[k]["kernel"]
+    assert "psnr_delta_vs_teacher_db" in aux["bf16"] and aux["bf16"]["meets_0.05_db"] == (abs(aux["bf16"]["psnr_delta_vs_teacher_db"]) <= 0.05)
+
+
+def test_train_line():
+    d = load("r03_train_bench.json")
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["scaling"] == "weak" and d["dtype"] == "bf16"
+    P = d["config"]["rays_per_gpu"] * d["config"]["samples_per_ray"]
+    assert abs(d["value"] - d["n_gpus"] * P / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+
+
+def test_pmc_lookup_needs_the_exact_instantiation(bench):
+    """roofline.traffic comes from a committed PMC summary only for the same mode / precision AND the full template
+    instantiation: the training forward of the bf16 kernel must never stand in for the bf16 render."""
+    t16, src16 = bench.pmc_traffic(bench.RENDER_KERNEL["fp16"], "render", "fp16")
+    tb, srcb = bench.pmc_traffic(bench.RENDER_KERNEL["bf16"], "render", "bf16")
+    assert t16 and tb and src16 != srcb and 3.0e7 < t16 < 5.0e7 and 3.0e7 < tb < 5.0e7
+    wrong = bench.pmc_traffic(bench.RENDER_KERNEL["bf16"], "render", "fp16")       # an r02 summary without arguments may hold it
+    assert wrong == (None, None) or wrong[0] < 5.0e7
+    assert bench.pmc_traffic("nerf_mlp_bf16_16_kernel<true, true, true>", "render", "bf16") == (None, None)
+    assert bench.pmc_traffic(bench.RENDER_KERNEL["fp32"], "render", "fp32") == (None, None)
+    tt, _ = bench.pmc_traffic("dw_gemm_kernel(", "train")
+    assert tt and tt > 2.5e9
