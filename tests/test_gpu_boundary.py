@@ -269,3 +269,36 @@ def test_render_ragged_shapes_vs_oracle(dev, oracle, synthetic, precision):
         got = render_nerf(empty.to(dev), net, 8)
     for a, b in zip(got, want):
         assert tuple(a.shape) == tuple(b.shape)
+
+
+def test_integration_stub_from_the_document(dev, golden, synthetic):
+    """INTEGRATION.md section 2 shows the ctypes stub a maintainer of the reference would add (pack + render_nerf over the
+    C ABI, keeping the reference's own Nerf for the weights).  This test runs THAT text -- the code block as printed, with
+    only the library's path filled in -- on a plain nn.Module holding the reference's 24 parameters, against golden G4."""
+    import os
+    import re
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.nets import Nerf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# utils/_nerf_amd\.py.*?)```", text, flags=re.S).group(1)
+    block = block.replace('ctypes.CDLL("libnerf_amd.so")', f'ctypes.CDLL("{_lib.LIB_PATH}")')
+    ns = {}
+    exec(compile(block, "INTEGRATION.md:stub", "exec"), ns)
+    g = golden("render_structured.npz")
+    net = Nerf().to(dev)                                   # stands in for the reference's module: same parameters, same order
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "structured"))
+    packed = ns["pack"](net)
+    rays = t(g["rays"]).to(dev)
+    saved = torch.get_rng_state()
+    try:
+        torch.manual_seed(int(g["N64_seed"]))              # the stub draws torch.rand(B, N) on the CPU like the reference
+        out = ns["render_nerf"](rays, packed, 64)
+    finally:
+        torch.set_rng_state(saved)
+    torch.cuda.synchronize()
+    assert not ns["out_of_range"](packed)
+    for name, o in zip(("rgb", "disp", "alpha", "acc", "w"), out):
+        want = g[f"N64_{name}"]
+        err = np.abs(o.cpu().numpy() - want).max() / max(1.0, np.abs(want).max())
+        assert err <= 7e-3, (name, err)                    # the fp16 tolerance of tests/test_gpu_parity.py

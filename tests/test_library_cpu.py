@@ -290,3 +290,36 @@ def test_stamp_tool_insertion_points():
     assert src.count("STAMP(") == 19                   # the macro + 18 stamps
     shipped = open(os.path.join(root, "nerf-simple_amd", "csrc", "mlp_bf16_16.hip")).read()
     assert "s_memtime" not in shipped and "STAMP" not in shipped     # the shipped kernel carries none
+
+
+def test_header_compiles_as_c_and_cxx(tmp_path):
+    """include/nerf_amd.h is the contract a C caller binds: it must compile as plain C99 and as C++ without warnings,
+    and every declared function must link against the shared library by its declared prototype."""
+    import shutil
+    import subprocess
+    from nerf_simple_amd import _lib
+    if shutil.which("gcc") is None or shutil.which("g++") is None:
+        pytest.skip("gcc / g++ not available")
+    inc = os.path.join(ROOT, "include")
+    syms = declared_symbols()
+    body = "#include \"nerf_amd.h\"\n#include <stdio.h>\nint main(void) {\n  void* p[] = {" + \
+           ", ".join(f"(void*){s}" for s in syms) + "};\n  printf(\"%d %d\\n\", (int)(sizeof p / sizeof p[0]), nerf_amd_abi_version());\n  return 0;\n}\n"
+    c_file, cxx_file = tmp_path / "abi.c", tmp_path / "abi.cc"
+    c_file.write_text(body)
+    cxx_file.write_text(body)
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-Wno-pedantic", "-I", inc, "-c", str(c_file), "-o",
+                    str(tmp_path / "abi_c.o")], check=True)
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I", inc, "-c", str(cxx_file), "-o", str(tmp_path / "abi_cc.o")],
+                   check=True)
+    # link the C object against the library: unresolved prototypes would fail here (no GPU needed to load it)
+    exe = tmp_path / "abi"
+    torch_lib = os.path.join(os.path.dirname(__import__("torch").__file__), "lib")
+    r = subprocess.run(["gcc", str(tmp_path / "abi_c.o"), "-o", str(exe), "-L", libdir, "-lnerf_amd", f"-Wl,-rpath,{libdir}",
+                        f"-Wl,-rpath-link,{torch_lib}", f"-Wl,-rpath,{torch_lib}", "-L", torch_lib, "-Wl,--allow-shlib-undefined"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    n, ver = out.stdout.decode().split()
+    assert int(n) == len(syms) and int(ver) == 3
