@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from nerf_simple_amd.utils import synthetic                      # noqa: E402
 from nerf_simple_amd.utils.nets import Nerf                      # noqa: E402
-from nerf_simple_amd.utils.rendering import render_view, render_hierarchical, generate_rays  # noqa: E402
+from nerf_simple_amd.utils.rendering import render_view, generate_rays  # noqa: E402
 from nerf_simple_amd.training import train_step                  # noqa: E402
 from nerf_simple_amd.utils.xyz import spherical_to_pose          # noqa: E402
 

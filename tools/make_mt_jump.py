@@ -16,7 +16,6 @@ start states of up to 2^M segments follow from the first by a doubling tree.
 Everything here is checked again by tests/test_oracle_golden.py (phi recomputed, a jump compared
 with plain sequential generation)."""
 import os
-import sys
 
 import numpy as np
 
