@@ -147,6 +147,17 @@ class Nerf(nn.Module):
         self.color_fc = nn.Sequential(nn.Linear(H + cd, H // 2), nn.ReLU(), nn.Linear(H // 2, 3))
         self._packed = {}       # (device, precision code) -> _Packed
 
+    # the packed images are a derived cache (device buffers, pinned words, events): copies and pickles of the module
+    # start without them and re-pack on first use
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_packed"] = {}
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._packed = {}
+
     # ---- packed-weight cache ------------------------------------------------
     def _fused_ok(self):
         return (self.Lp, self.Ld, self.H) == (10, 4, 256)

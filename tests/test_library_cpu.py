@@ -149,6 +149,21 @@ def test_oracle_single_sample_is_the_reference_degenerate_case(oracle, synthetic
     assert float(rgb.abs().max()) == 0 and float(acc.abs().max()) == 0 and torch.isnan(disp).all()
 
 
+def test_module_copies_leave_the_packed_cache_behind(synthetic):
+    """copy.deepcopy / pickle of a Nerf carry the 24 parameters and the precision, not the derived weight images."""
+    import copy
+    import pickle
+    import torch
+    from nerf_simple_amd.utils.nets import Nerf, _Packed
+    a = Nerf(precision="bf16")
+    a.load_state_dict(synthetic.synthetic_state_dict(2, "default"))
+    a._packed[("fake", 1)] = _Packed((), torch.zeros(4, dtype=torch.uint8))      # stands in for a device image
+    for b in (copy.deepcopy(a), pickle.loads(pickle.dumps(a))):
+        assert b._packed == {} and b.precision == "bf16"
+        assert all(torch.equal(x, y) for x, y in zip(a.state_dict().values(), b.state_dict().values()))
+    assert len(a._packed) == 1
+
+
 def test_host_camera_helpers(golden):
     import torch
     import numpy as np
