@@ -302,3 +302,38 @@ def test_integration_stub_from_the_document(dev, golden, synthetic):
         want = g[f"N64_{name}"]
         err = np.abs(o.cpu().numpy() - want).max() / max(1.0, np.abs(want).max())
         assert err <= 7e-3, (name, err)                    # the fp16 tolerance of tests/test_gpu_parity.py
+
+
+def test_composite_special_values_like_the_reference(dev, oracle):
+    """volume_render on values a diverging or untrained network can emit -- sigma at and around the softplus threshold,
+    huge, infinite, NaN; colours huge, infinite, NaN; coincident sample positions (delta = 0) -- against the oracle's
+    torch ops: NaNs in the same places (torch.max's NaN propagation in the disparity, 0 * inf in the products), finite
+    values to the compositor's tolerance, infinities equal."""
+    from nerf_simple_amd.utils.rendering import volume_render
+    sig_vals = torch.tensor([0.0, 1e-8, -1e-8, 1.0, -1.0, 19.9, 20.0, 20.1, -19.9, 100.0, -100.0, 1e4, -1e4, float("inf"),
+                             float("-inf"), float("nan")])
+    col_vals = torch.tensor([0.0, 1.0, -1.0, 0.25, 1e30, -1e30, float("inf"), float("nan")])
+    gen = torch.Generator().manual_seed(31)
+    for B, N in ((64, 16), (32, 64), (16, 130)):
+        raw = torch.empty(B, N, 4)
+        raw[..., 3] = sig_vals[torch.randint(0, len(sig_vals), (B, N), generator=gen)]
+        raw[..., :3] = col_vals[torch.randint(0, len(col_vals), (B, N, 3), generator=gen)]
+        # most entries ordinary, so that the special ones meet ordinary neighbours
+        plain = torch.rand(B, N, generator=gen) < 0.7
+        raw[plain] = torch.randn(int(plain.sum()), 4, generator=gen)
+        ts = torch.sort(torch.rand(B, N, generator=gen) * 4 + 2, dim=1).values
+        ts[:, 3] = ts[:, 2]                                  # a coincident pair: delta = 0
+        d = torch.randn(B, 3, generator=gen)
+        want = oracle.volume_render(raw, ts, d)
+        got = volume_render(raw.to(dev), ts.to(dev), d.to(dev))
+        for name, a, b in zip(("rgb", "disp", "alpha", "acc", "w"), got, want):
+            a, b = a.cpu().numpy(), b.numpy()
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (B, N, name, int(np.isnan(a).sum()), int(np.isnan(b).sum()))
+            inf = np.isinf(b)
+            assert np.array_equal(a[inf], b[inf]), (B, N, name)
+            fin = np.isfinite(b)
+            assert np.isfinite(a[fin]).all(), (B, N, name)
+            if fin.any():
+                # sums of terms up to 1e30 cancel: the bound is relative to the largest finite term a ray can hold
+                scale = max(1.0, float(np.abs(b[fin]).max()))
+                assert np.abs(a[fin] - b[fin]).max() <= 1e-4 * scale, (B, N, name, np.abs(a[fin] - b[fin]).max(), scale)
