@@ -172,7 +172,9 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, const float (&in)[64], 
         sigma = r[0];
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) out[4 * T + i] = D.relu ? fmaxf(r[i], 0.f) : r[i];
+        // ReLU as torch computes it: NaN stays NaN (fmaxf / v_max_f32 would return the 0), so that a non-finite input
+        // or weight shows in the outputs exactly as it does in the reference (utils/nets.py:16-26, nn.ReLU)
+        for (int i = 0; i < 4; ++i) out[4 * T + i] = D.relu ? (r[i] < 0.f ? 0.f : r[i]) : r[i];
     }
     if constexpr (QB == Q) publish_and_prefetch();
 }

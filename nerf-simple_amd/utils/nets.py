@@ -22,8 +22,8 @@ DEFAULT_PRECISION = "fp16"
 
 class _Packed:
     """One packed weight image of a module: the device buffer, the parameter versions it was derived from,
-    and -- for the fp16 image -- the state of the range guard (guarded_launch)."""
-    __slots__ = ("stamp", "buf", "probed", "demoted", "host", "event")
+    and -- for the 16-bit images -- the state of the range guard (guarded_launch)."""
+    __slots__ = ("stamp", "buf", "probed", "demoted", "host", "event")     # guard state: 16-bit images only
 
     def __init__(self, stamp, buf):
         self.stamp, self.buf = stamp, buf
@@ -31,7 +31,7 @@ class _Packed:
 
     def reset_guard(self):
         self.probed = False          # the status word has been read once (blocking) after a launch with these weights
-        self.demoted = False         # these weights left the fp16 range: fp16 requests render with bf16 operands
+        self.demoted = False         # flagged: requests for this precision go to the next one (fp16 -> bf16 -> fp32)
         self.host = None             # pinned int32[2]: lazily copied status words of later launches
         self.event = None            # recorded behind that copy
 
@@ -47,62 +47,68 @@ def packed_status(packed, code):
     return 0 if off < 0 else _status_flags(packed[off:off + 8].view(torch.int32).cpu())
 
 
+_NEXT_PRECISION = {_lib.FP16: _lib.BF16, _lib.BF16: _lib.F32}
+
+
 def guarded_launch(nets, code, launch):
     """Run ``launch(code, [packed image of each net])`` -- which enqueues kernels through the C ABI and returns
-    their outputs -- under the fp16 range guard.
+    their outputs -- under the range guard of the 16-bit kernels.
 
     The reference network is fp32 with no range limit (utils/nets.py:16-32); fp16 MFMA operands overflow beyond
-    65504 and an overflowed activation ends as inf / NaN pixels.  The 16-bit kernels therefore OR a sticky flag
-    into the status word behind the packed image whenever a point's (rgb, sigma) is not finite, and the packer
+    65504, and the 16-bit kernels' integer ReLU does not even keep the resulting NaN (it zeroes one whose sign bit is
+    set): an overflow ends as NaN pixels or as finite garbage.  Those kernels therefore set a sticky flag in the
+    status block behind the packed image whenever a point shows a non-finite accumulator or output, and the packer
     flags weights that do not fit (include/nerf_amd.h nerf_amd_packed_status_offset).  Policy, per weight set:
-      * the FIRST fp16 launch is followed by one blocking read of the word; if it is set, a UserWarning is
-        issued, the module is demoted to bf16 operands for these weights, and the call is repeated in bf16 --
-        the caller never sees the NaN pixels;
-      * later launches (other rays may still overflow) copy the word to pinned memory asynchronously and the
-        NEXT call looks at it without waiting: demotion then takes effect from that call on, with the warning
-        naming the earlier render.
-    Other precisions run unguarded (bf16 has fp32's exponent range)."""
-    if code != _lib.FP16:
-        return launch(code, [n.packed_weights(code) for n in nets])
-    ents = [n._packed_entry(_lib.FP16) for n in nets]
-
-    def in_bf16():
-        return launch(_lib.BF16, [n.packed_weights(_lib.BF16) for n in nets])
-
-    if any(e.demoted for e in ents):
-        return in_bf16()
-    dev = ents[0].buf.device
-    capturing = torch.cuda.is_current_stream_capturing()
-    off = int(_lib.lib().nerf_amd_packed_status_offset(_lib.FP16))
-    if not capturing:
+      * the FIRST launch of a 16-bit precision is followed by one blocking read of the flags; if one is set, a
+        UserWarning is issued, the module is demoted for these weights -- fp16 to bf16 operands (fp32's exponent range),
+        bf16 to the fp32 kernel, whose ReLU keeps NaN like torch's, so that non-finite inputs or weights show in the
+        outputs exactly as in the reference -- and the call is repeated: the caller never sees the bad pixels;
+      * later launches (other rays may still overflow) copy the flags to pinned memory asynchronously and the NEXT
+        call looks at them without waiting: demotion then takes effect from that call on, with the warning naming the
+        earlier render."""
+    off = None
+    while code != _lib.F32:
+        ents = [n._packed_entry(code) for n in nets]
+        if any(e.demoted for e in ents):
+            code = _NEXT_PRECISION[code]
+            continue
+        dev = ents[0].buf.device
+        capturing = torch.cuda.is_current_stream_capturing()
+        if off is None:
+            off = int(_lib.lib().nerf_amd_packed_status_offset(code))      # the same for both 16-bit images
         late = 0
-        for n, e in zip(nets, ents):
-            if e.event is not None and e.event.query():
-                flags, e.event = _status_flags(e.host), None
-                if flags:
-                    n._demote(e, flags, "an earlier render")
-                    late |= flags
+        if not capturing:
+            for n, e in zip(nets, ents):
+                if e.event is not None and e.event.query():
+                    flags, e.event = _status_flags(e.host), None
+                    if flags:
+                        n._demote(e, code, flags, "an earlier render")
+                        late |= flags
         if late:
-            return in_bf16()
-    out = launch(_lib.FP16, [e.buf for e in ents])
-    if capturing:
-        return out
-    redo = False
-    for n, e in zip(nets, ents):
-        word = e.buf[off:off + 8].view(torch.int32)     # [non-finite output seen, weight out of range]
-        if not e.probed:
-            flags = _status_flags(word.cpu())           # blocking, once per weight set
-            e.probed = True
-            if flags:
-                n._demote(e, flags, "this render (repeated with bf16 operands)")
-                redo = True
-        elif e.event is None:
-            if e.host is None:
-                e.host = torch.zeros(2, dtype=torch.int32).pin_memory()
-            e.host.copy_(word, non_blocking=True)
-            e.event = torch.cuda.Event()
-            e.event.record(torch.cuda.current_stream(dev))
-    return in_bf16() if redo else out
+            code = _NEXT_PRECISION[code]
+            continue
+        out = launch(code, [e.buf for e in ents])
+        if capturing:
+            return out
+        redo = False
+        for n, e in zip(nets, ents):
+            word = e.buf[off:off + 8].view(torch.int32)     # [non-finite value seen, weight out of range]
+            if not e.probed:
+                flags = _status_flags(word.cpu())           # blocking, once per weight set and precision
+                e.probed = True
+                if flags:
+                    n._demote(e, code, flags, "this render (repeated)")
+                    redo = True
+            elif e.event is None:
+                if e.host is None:
+                    e.host = torch.zeros(2, dtype=torch.int32).pin_memory()
+                e.host.copy_(word, non_blocking=True)
+                e.event = torch.cuda.Event()
+                e.event.record(torch.cuda.current_stream(dev))
+        if not redo:
+            return out
+        code = _NEXT_PRECISION[code]
+    return launch(code, [n.packed_weights(code) for n in nets])
 
 
 class Nerf(nn.Module):
@@ -193,16 +199,20 @@ class Nerf(nn.Module):
         self._packed[key] = _Packed(stamp, packed)
         return self._packed[key]
 
-    def _demote(self, entry, flags, where):
+    def _demote(self, entry, code, flags, where):
         entry.demoted = True
         why = []
         if flags & _lib.STATUS_WEIGHT_RANGE:
             why.append("a weight beyond 65504")
         if flags & _lib.STATUS_NONFINITE:
-            why.append(f"a non-finite network output in {where}")
-        warnings.warn("Nerf: fp16 MFMA operands left their range (" + " and ".join(why) + "); these weights now render with "
-                      "bf16 operands (precision='bf16': fp32's exponent range, 8-bit mantissa) until they change",
-                      UserWarning, stacklevel=4)
+            why.append(f"a non-finite value inside the network in {where}")
+        if code == _lib.FP16:
+            msg = ("Nerf: fp16 MFMA operands left their range (" + " and ".join(why) + "); these weights now render with "
+                   "bf16 operands (precision='bf16': fp32's exponent range, 8-bit mantissa) until they change")
+        else:
+            msg = ("Nerf: " + " and ".join(why) + " with bf16 operands (non-finite inputs or weights?); these weights now "
+                   "render with the fp32 kernel, which propagates NaN / inf like the reference, until they change")
+        warnings.warn(msg, UserWarning, stacklevel=4)
 
     def repack_from_flat(self, flat):
         """Re-derive every packed image already in use from a flat fp32 parameter

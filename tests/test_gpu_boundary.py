@@ -337,3 +337,36 @@ def test_composite_special_values_like_the_reference(dev, oracle):
                 # sums of terms up to 1e30 cancel: the bound is relative to the largest finite term a ray can hold
                 scale = max(1.0, float(np.abs(b[fin]).max()))
                 assert np.abs(a[fin] - b[fin]).max() <= 1e-4 * scale, (B, N, name, np.abs(a[fin] - b[fin]).max(), scale)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
+def test_non_finite_inputs_propagate_like_the_reference(dev, oracle, synthetic, precision):
+    """Garbage in: a ray with a NaN origin and one with an infinite direction.  In the reference every sample of such a
+    ray is NaN through the network (torch's ReLU keeps NaN), its outputs are NaN, and every other ray is untouched.  The
+    fp32 kernel does the same; the 16-bit kernels' integer ReLU would not (it zeroes a NaN whose sign bit is set), so
+    their range guard sends these weights to the fp32 kernel, with a warning -- the result has the reference's NaNs."""
+    import warnings as _w
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import render_nerf
+    sd = synthetic.synthetic_state_dict(0, "structured")
+    rays = scene_rays(oracle, synthetic, 6).clone()
+    rays[5, 1] = float("nan")
+    rays[17, 4] = float("inf")
+    N = 32
+    u = torch.rand(rays.shape[0], N, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        want = oracle.render_nerf(rays, sd, N, u=u)
+    bad = torch.isnan(want[0]).any(dim=1)
+    assert bad[5] and bad[17] and int(bad.sum()) == 2
+    net = Nerf(precision=precision).to(dev)
+    net.load_state_dict(sd)
+    with torch.no_grad(), _w.catch_warnings(record=True) as caught:
+        _w.simplefilter("always")
+        got = render_nerf(rays.to(dev), net, N, u=u.to(dev))
+    if precision != "fp32":
+        assert any("non-finite" in str(w.message) for w in caught), [str(w.message) for w in caught]
+    for name, a, b in zip(("rgb", "disp", "alpha", "acc", "w"), got, want):
+        a, b = a.cpu().numpy(), b.numpy()
+        assert np.array_equal(np.isnan(a), np.isnan(b)), (precision, name)
+        ok = ~np.isnan(b)
+        assert np.abs(a[ok] - b[ok]).max() <= 1e-4 * max(1.0, np.abs(b[ok]).max()), (precision, name)   # it IS the fp32 kernel by now
