@@ -400,7 +400,7 @@ class GraphedTrainStep:
     # ---- the two launch sequences --------------------------------------------------
     def _forward_backward(self, bucket=0):
         """Main branch: forward -> compositing + MSE gradient + compositing backward -> dX chain -> dW (all products,
-        or with ``bucket`` = 1 only those of the late layers: _late_gradients adds the rest).
+        or with ``bucket`` = 1 only those of the late layers: _head_gradients adds the rest).
         Side branch (a fork / join inside the captured graph): the encoder rows of the dW products
         beside the forward, then loss value + gradient-vector zero fill + d_raw pack beside the dX chain."""
         lib, B, N_, P = _lib.lib(), self.B, self.N, self.B * self.N
