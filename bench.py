@@ -408,13 +408,10 @@ def aux_configs(dev, sd, rays_800):
     gt5 = torch.rand(TRAIN_RAYS, 3, generator=gen).to(dev)
     for N, steps in ((64, 600), (128, 300)):
         net = net_of("bf16", 0, "default")
-        stepper = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), TRAIN_RAYS, N)
-        us = [torch.rand(TRAIN_RAYS, N, generator=gen).to(dev) for _ in range(2)]
-        k = [0]
+        stepper = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), TRAIN_RAYS, N, device_rng=True, seed=7)
 
         def one():
-            stepper.step(rays5, gt5, u=us[k[0] & 1])
-            k[0] += 1
+            stepper.step(rays5, gt5)                  # fresh jitter every step, drawn in the kernels
 
         ms = event_timed(one, steps, 30, dev)
         P = TRAIN_RAYS * N
@@ -572,15 +569,16 @@ def run_train(args):
     net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
     parallel.broadcast_parameters(net)
     opt = FusedAdam(net, lr=5e-4)
+    # fresh stratified jitter every step, drawn inside the kernels by the counter RNG (seed + step count from device
+    # memory: the replayed graphs carry no per-step argument); each rank's ray ids are offset so ranks draw differently
     stepper = GraphedTrainStep(net, opt, B, N, group=(dist.group.WORLD if multi else None), timing=multi,
-                               buckets=int(os.environ.get("NERF_BENCH_BUCKETS", "1")))
-    # synthetic batch: 4096 rays of a 64x64 camera on this rank's own azimuth, random targets, four
-    # pre-drawn jitter tables cycled through (the reference's per-step host work is out of the timed path)
+                               buckets=int(os.environ.get("NERF_BENCH_BUCKETS", "1")), device_rng=True, seed=1234,
+                               ray_id0=rank * B)
+    # synthetic batch: 4096 rays of a 64x64 camera on this rank's own azimuth, random targets
     pose = torch.from_numpy(spherical_to_pose(4, -30, 20.0 * rank)).float()
     rays = camera_rays([pose], [64, 64, synthetic.focal_from_fov(64)]).to(dev).contiguous()
     gen = torch.Generator().manual_seed(100 + rank)
     gt = torch.rand(B, 3, generator=gen).to(dev)
-    us = [torch.rand(B, N, generator=gen).to(dev) for _ in range(4)]
     decay = lr_decay_factor(5e-4, 5e-5, 10000)              # reference configs/lego.yaml lr_init / lr_final shape
     it = [0]
 
@@ -590,7 +588,7 @@ def run_train(args):
         if record and not timed[0]:
             timed[0] = True
             stepper.reset_timing()                  # the exchange times are of the timed steps only
-        stepper.step(rays, gt, u=us[it[0] & 3], decay=decay)
+        stepper.step(rays, gt, decay=decay)
         it[0] += 1
 
     elapsed = timed_loop(step, args, dist, dev, world)
@@ -627,6 +625,7 @@ def run_train(args):
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "train.py step: 4096 rays x 64 samples per GPU, bf16, FusedAdam, hipGraph replay "
                                    "(BASELINE config 5)",
+                       "jitter": "fresh per step, device counter RNG inside the timed step",
                        "rays_per_gpu": B, "samples_per_ray": N, "global_batch_rays": B * world,
                        "parallelism": f"data-parallel x{world}" + (" + all_reduce of the flat 2.38 MB gradient" if multi else "")},
             "ranks": seen, "final_loss": loss,

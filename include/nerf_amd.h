@@ -45,6 +45,10 @@ extern "C" {
 /* flags of nerf_amd_render_forward / nerf_amd_mlp_forward_rays */
 #define NERF_AMD_TS_GIVEN   1u  /* `u` holds sample positions ts[B,N], not jitter */
 #define NERF_AMD_DEVICE_RNG 2u  /* `u` ignored (may be NULL): jitter from the counter RNG */
+#define NERF_AMD_SEED_IN_MEMORY 4u /* with NERF_AMD_DEVICE_RNG: `u` is the DEVICE ADDRESS of a uint64 that is added to
+                                    * `seed` when the kernel runs -- a launch captured into a hipGraph is replayed with
+                                    * frozen arguments, and this is how every replay of a training step draws fresh
+                                    * jitter (the reference draws torch.rand(B,N) anew per call, utils/rendering.py:28) */
 
 /* ---- introspection (host only, no GPU needed) ------------------------------ */
 int      nerf_amd_abi_version(void);

@@ -19,7 +19,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
 
 F32, BF16, FP16, BF16_BWD = 0, 1, 2, 3
-FLAG_TS_GIVEN, FLAG_DEVICE_RNG = 1, 2
+FLAG_TS_GIVEN, FLAG_DEVICE_RNG, FLAG_SEED_IN_MEMORY = 1, 2, 4
 STATUS_NONFINITE, STATUS_WEIGHT_RANGE = 1, 2
 _PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, F32: F32,
                "bf16": BF16, "bfloat16": BF16, BF16: BF16,

@@ -48,6 +48,16 @@ inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool bad_precision(int p) { return p != NERF_AMD_F32 && p != NERF_AMD_BF16 && p != NERF_AMD_FP16; }
 inline bool bad_image(int p) { return bad_precision(p) && p != NERF_AMD_BF16_BWD; }
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+// the jitter arguments of every rays-mode entry point: explicit u / ts, the counter RNG, or the counter RNG with its
+// seed offset in device memory (then `u` is that address)
+inline bool bad_jitter(uint32_t flags, const float* u, const float* tbins) {
+    if (flags & NERF_AMD_SEED_IN_MEMORY) {
+        if (!(flags & NERF_AMD_DEVICE_RNG) || (flags & NERF_AMD_TS_GIVEN) || !u) return true;
+    } else if (!(flags & NERF_AMD_DEVICE_RNG) && !u) {
+        return true;
+    }
+    return !(flags & NERF_AMD_TS_GIVEN) && !tbins;
+}
 
 // the fused render kernels (sampling + MLP + compositing in one launch) serve rays of up to
 // FUSED_RENDER_MAX_N samples, in every precision
@@ -174,8 +184,7 @@ int nerf_amd_query_points(const float* rays, const float* u, const float* tbins,
     if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
     if (B == 0) return 0;
     if (!rays || !query_pts) return NERF_AMD_EINVAL;
-    if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
-    if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+    if (bad_jitter(flags, u, tbins)) return NERF_AMD_EINVAL;
     MlpArgs a{};
     a.rays = rays; a.u = u; a.tbins = tbins; a.ts_out = ts;
     a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
@@ -261,8 +270,7 @@ int nerf_amd_sample_encode(const float* rays, const float* u, const float* tbins
     if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
     if (B == 0) return 0;
     if (!rays || !posx || !posd) return NERF_AMD_EINVAL;
-    if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
-    if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+    if (bad_jitter(flags, u, tbins)) return NERF_AMD_EINVAL;
     MlpArgs a{};
     a.rays = rays; a.u = u; a.tbins = tbins; a.ts_out = ts;
     a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
@@ -275,8 +283,7 @@ int nerf_amd_mlp_forward_rays(const float* rays, const float* u, const float* tb
     if (B < 0 || N <= 0 || bad_precision(precision)) return NERF_AMD_EINVAL;
     if (B == 0) return 0;
     if (!rays || !packed || !raw) return NERF_AMD_EINVAL;
-    if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
-    if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+    if (bad_jitter(flags, u, tbins)) return NERF_AMD_EINVAL;
     MlpArgs a{};
     a.rays = rays; a.u = u; a.tbins = tbins; a.packed = packed; a.raw = raw; a.ts_out = ts;
     a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
@@ -292,8 +299,7 @@ int nerf_amd_render_forward(const float* rays, const float* u, const float* tbin
     if (!rgb || !disp || !acc) return NERF_AMD_EINVAL;
     if (fused_render(precision, N)) {
         if (!rays || !packed) return NERF_AMD_EINVAL;
-        if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
-        if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+        if (bad_jitter(flags, u, tbins)) return NERF_AMD_EINVAL;
         MlpArgs a{};
         a.rays = rays; a.u = u; a.tbins = tbins; a.packed = packed;
         a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
@@ -318,8 +324,7 @@ int nerf_amd_render_pixels_forward(const float* rays, const float* u, const floa
     if (!pixels) return NERF_AMD_EINVAL;
     if (fused_render(precision, N)) {
         if (!rays || !packed) return NERF_AMD_EINVAL;
-        if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
-        if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+        if (bad_jitter(flags, u, tbins)) return NERF_AMD_EINVAL;
         MlpArgs a{};
         a.rays = rays; a.u = u; a.tbins = tbins; a.packed = packed;
         a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
@@ -422,8 +427,7 @@ int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* t
     if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
     if (B == 0) return 0;
     if (!rays || !packed || !raw || !acts) return NERF_AMD_EINVAL;
-    if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
-    if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+    if (bad_jitter(flags, u, tbins)) return NERF_AMD_EINVAL;
     MlpArgs a{};
     a.rays = rays; a.u = u; a.tbins = tbins; a.packed = packed; a.raw = raw; a.ts_out = ts; a.acts = acts;
     a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
@@ -463,8 +467,7 @@ int nerf_amd_sample_encode_bf16(const float* rays, const float* u, const float* 
     if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
     if (B == 0) return 0;
     if (!rays || !posx64 || !posd32) return NERF_AMD_EINVAL;
-    if (!(flags & NERF_AMD_DEVICE_RNG) && !u) return NERF_AMD_EINVAL;
-    if (!(flags & NERF_AMD_TS_GIVEN) && !tbins) return NERF_AMD_EINVAL;
+    if (bad_jitter(flags, u, tbins)) return NERF_AMD_EINVAL;
     MlpArgs a{};
     a.rays = rays; a.u = u; a.tbins = tbins; a.ts_out = ts;
     a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;

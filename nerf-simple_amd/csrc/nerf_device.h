@@ -18,6 +18,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 #define NERF_FLAG_TS_GIVEN 1u
 #define NERF_FLAG_DEVICE_RNG 2u
+#define NERF_FLAG_SEED_IN_MEMORY 4u     // with DEVICE_RNG: `u` is the device address of a uint64 added to `seed` at run time
 
 // Arguments of the fused sampling + encoding + MLP kernels.
 struct MlpArgs {
@@ -176,13 +177,24 @@ __device__ __forceinline__ RaySample split_point(long long p, int N) {
     return RaySample{b, (int)(p - b * N)};
 }
 
+// The seed of the counter RNG.  A launch captured into a hipGraph is replayed with its arguments frozen; with
+// NERF_FLAG_SEED_IN_MEMORY the `u` argument is not jitter but the device address of a 64-bit word that is added to the
+// seed when the kernel RUNS, so every replay of a training step draws fresh jitter (one scalar load per use).
+__device__ __forceinline__ unsigned long long effective_seed(const MlpArgs& a) {
+    if (!(a.flags & NERF_FLAG_SEED_IN_MEMORY)) return a.seed;
+    const unsigned long long v = *reinterpret_cast<const unsigned long long*>(a.u);
+    // wave-uniform by construction: keep it in scalar registers whatever load the compiler picked
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return a.seed + (((unsigned long long)hi << 32) | lo);
+}
+
 // the counter RNG's draw for (ray b, sample i) of this launch (FLAG_DEVICE_RNG)
 __device__ __forceinline__ float device_rng_uniform(const MlpArgs& a, RaySample rs) {
     // The seed passes through an empty asm so that the ten rounds' key schedule (k += const, wave-uniform)
     // is recomputed here -- 20 scalar adds -- instead of being hoisted out of the persistent tile loop as
     // 20 live SGPRs, which the fused render kernel could only keep by spilling them to VGPR lanes
     // (v_writelane / v_readlane + hazard nops inside every Philox round).
-    unsigned long long seed = a.seed;
+    unsigned long long seed = effective_seed(a);
     asm volatile("" : "+s"(seed));
     return philox_uniform(seed, (unsigned long long)((a.ray_id0 + rs.b) * a.N + rs.i));
 }
@@ -205,7 +217,7 @@ __device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long 
     } else {
         float u;
         if (a.flags & NERF_FLAG_DEVICE_RNG)
-            u = have_u ? u_pre : philox_uniform(a.seed, (unsigned long long)((a.ray_id0 + b) * a.N + i));
+            u = have_u ? u_pre : philox_uniform(effective_seed(a), (unsigned long long)((a.ray_id0 + b) * a.N + i));
         else
             u = __builtin_nontemporal_load(a.u + p);
         const float bin_diff = __fsub_rn(a.tbins[1], a.tbins[0]);

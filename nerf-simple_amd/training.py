@@ -288,11 +288,12 @@ class _HyperRing:
     Each slot is reused only after the event recorded behind its own copy has completed."""
 
     def __init__(self, slots=8):
-        self.bufs = [torch.zeros(6, dtype=torch.float32).pin_memory() for _ in range(slots)]
+        # 6 floats for Adam + one int64 (as two float slots): the jitter seed offset of the step (device_rng)
+        self.bufs = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(slots)]
         self.events = [None] * slots
         self.k = 0
 
-    def push(self, values, dst):
+    def push(self, values, dst, seed_offset=0):
         i = self.k % len(self.bufs)
         self.k += 1
         if self.events[i] is not None:
@@ -300,6 +301,7 @@ class _HyperRing:
         h = self.bufs[i]
         for j, v in enumerate(values):
             h[j] = v
+        h[6:8].view(torch.int64)[0] = int(seed_offset)
         dst.copy_(h, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dst.device))
@@ -339,10 +341,17 @@ class GraphedTrainStep:
     corrections from a 6-float device vector (nerf_amd_adam_step_hyper) fed through a ring of
     pinned buffers.  ``optimizer`` must be ``optim.FusedAdam``.
 
+    ``device_rng=True``: the jitter is drawn inside the kernels by the counter RNG instead (no ``u`` traffic, no host
+    work, no wait for the CPU generator's state): seed = ``seed`` + the step count, which travels with the Adam scalars
+    (the launches carry NERF_AMD_SEED_IN_MEMORY, so the replayed graph reads the current value); ``ray_id0`` offsets
+    the ray ids of this replica, so data-parallel ranks given rank * n_rays draw different jitter.  Same values as the
+    eager ``train_step(..., device_rng=True, seed=seed + k, ray_id0=ray_id0)`` at step k (1-based).
+
     ``step(rays, gt, u=None, decay=1.0)`` returns the loss as a 0-d device tensor (no sync).
     """
 
-    def __init__(self, net, optimizer, n_rays, N, *, tn=2, tf=6, group=None, timing=False, buckets=1):
+    def __init__(self, net, optimizer, n_rays, N, *, tn=2, tf=6, group=None, timing=False, buckets=1,
+                 device_rng=False, seed=0, ray_id0=0):
         from . import parallel
         from .optim import FusedAdam
         from .utils.rendering import _tbins
@@ -357,6 +366,7 @@ class GraphedTrainStep:
         self.exchange = group is not None and parallel.collectives_active(group)
         self.bucketed = self.exchange and buckets == 2
         self.timing, self._events = bool(timing), []
+        self.device_rng, self.seed, self.ray_id0 = bool(device_rng), int(seed), int(ray_id0)
         self.B, self.N = int(n_rays), int(N)
         dev = optimizer.flat.device
         self.dev = dev
@@ -386,7 +396,7 @@ class GraphedTrainStep:
         for b in (1, 2):
             _lib.check(lib.nerf_amd_grad_bucket_range(b, ctypes.byref(first), ctypes.byref(count)), "nerf_amd_grad_bucket_range")
             self.buckets.append(self.grads[first.value:first.value + count.value])
-        self.hyper = torch.zeros(6, **f32)
+        self.hyper = torch.zeros(8, **f32)                 # [lr, b1, b2, eps, 1-b1^t, sqrt(1-b2^t), seed offset (int64)]
         self._ring = _HyperRing()
         self._side = torch.cuda.Stream(dev)
         # parameters' .grad are views of the flat gradient vector, as after the eager fused backward
@@ -411,11 +421,18 @@ class GraphedTrainStep:
         side = self._side
         st, ss = ctypes_stream(main), ctypes_stream(side)
         side.wait_stream(main)
-        # same sample positions as the forward draws them: ts = f(u) bit for bit (flags 0, the same u / tbins)
-        ck(lib.nerf_amd_sample_encode_bf16(ptr(self.rays), ptr(self.u), ptr(self.tbins), 0, 0, 0,
+        if self.device_rng:
+            # counter RNG; `u` = the address of this step's seed offset inside the hyper vector (int64 at float slot 6)
+            import ctypes
+            jit = ctypes.c_void_p(self.hyper.data_ptr() + 24)
+            flags, seed, rid = _lib.FLAG_DEVICE_RNG | _lib.FLAG_SEED_IN_MEMORY, self.seed, self.ray_id0
+        else:
+            jit, flags, seed, rid = ptr(self.u), 0, 0, 0
+        # same sample positions as the forward draws them: ts = f(jitter) bit for bit (the same flags / u / seed / tbins)
+        ck(lib.nerf_amd_sample_encode_bf16(ptr(self.rays), jit, ptr(self.tbins), flags, seed, rid,
                                            ptr(self.posx), ptr(self.posd), None, B, N_, ss),
            "nerf_amd_sample_encode_bf16")
-        ck(lib.nerf_amd_mlp_forward_train(ptr(self.rays), ptr(self.u), ptr(self.tbins), ptr(packed), 0, 0, 0,
+        ck(lib.nerf_amd_mlp_forward_train(ptr(self.rays), jit, ptr(self.tbins), ptr(packed), flags, seed, rid,
                                           ptr(self.raw), ptr(self.ts), ptr(self.acts), B, N_, st),
            "nerf_amd_mlp_forward_train")
         # only rgb feeds the loss (train.py:52): disparity, alpha, acc, w are not materialised
@@ -450,7 +467,7 @@ class GraphedTrainStep:
         pg = self.opt.param_groups[0]
         b1, b2 = float(pg["betas"][0]), float(pg["betas"][1])
         self._ring.push((float(pg["lr"]), b1, b2, float(pg["eps"]), 1.0 - b1 ** step, (1.0 - b2 ** step) ** 0.5),
-                        self.hyper)
+                        self.hyper, seed_offset=step)
 
     def _capture(self):
         with torch.cuda.device(self.dev):
@@ -487,12 +504,16 @@ class GraphedTrainStep:
             raise RuntimeError(f"GraphedTrainStep was captured for rays {tuple(self.rays.shape)}, gt {tuple(self.gt.shape)}")
         self.rays.copy_(rays, non_blocking=True)
         self.gt.copy_(gt, non_blocking=True)
-        if u is None:
-            # the reference's one draw per call from torch's CPU generator, continued on the device
-            from .utils.host_rng import reference_rand
-            u, pending = reference_rand(self.B, self.N, self.dev)
-            pending.finish()
-        self.u.copy_(u, non_blocking=True)
+        if self.device_rng:
+            if u is not None:
+                raise RuntimeError("this GraphedTrainStep draws its jitter on the device (device_rng=True): u must be None")
+        else:
+            if u is None:
+                # the reference's one draw per call from torch's CPU generator, continued on the device
+                from .utils.host_rng import reference_rand
+                u, pending = reference_rand(self.B, self.N, self.dev)
+                pending.finish()
+            self.u.copy_(u, non_blocking=True)
         self.opt.step_count += 1
         self._set_hyper(self.opt.step_count)
         self.graph_a.replay()

@@ -614,3 +614,46 @@ def test_fused_adam_matches_torch(dev, golden, synthetic):
     # (measured: mean 1.2e-6, 2.3 % of the entries beyond 1e-5; the bound leaves room for other orders)
     d = (pa - pb).abs()
     assert float(d.max()) <= 6 * 5e-4 and float(d.mean()) <= 1e-5 and float((d > 1e-5).float().mean()) <= 0.06
+
+
+def test_graphed_step_with_device_jitter(dev, golden, synthetic):
+    """GraphedTrainStep(device_rng=True): every replay draws fresh stratified jitter inside the kernels (counter RNG,
+    seed + step count read from device memory through NERF_AMD_SEED_IN_MEMORY -- the captured launches carry no per-step
+    argument).  Step k's gradient equals the eager train_step(device_rng=True, seed=seed + k, ray_id0=...) gradient at
+    the same weights (lr = 0 keeps them fixed), consecutive steps see different sample positions, and another ray-id
+    offset (another data-parallel rank) another jitter."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.optim import FusedAdam
+    from nerf_simple_amd.training import train_step, GraphedTrainStep
+    g = golden("train.npz")
+    rays, gt, N = t(g["rays"]).to(dev), t(g["gt"]).to(dev), int(g["N"])
+    B = rays.shape[0]
+
+    def fresh():
+        net = Nerf(precision="bf16").to(dev)
+        net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+        return net
+
+    net = fresh()
+    stepper = GraphedTrainStep(net, FusedAdam(net, lr=0.0), B, N, device_rng=True, seed=40, ray_id0=3 * B)
+    with pytest.raises(RuntimeError, match="device_rng"):
+        stepper.step(rays, gt, u=torch.zeros(B, N, device=dev))
+    seen = []
+    for k in (1, 2, 3):
+        loss = float(stepper.step(rays, gt))
+        torch.cuda.synchronize()
+        seen.append((loss, stepper.ts.clone(), stepper.grads.clone()))
+        ref = fresh()
+        opt = torch.optim.SGD(ref.parameters(), lr=0.0)
+        want_loss = float(train_step(ref, opt, rays, gt, N, device_rng=True, seed=40 + k, ray_id0=3 * B))
+        want = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+        assert abs(loss - want_loss) <= 1e-6 * abs(want_loss), (k, loss, want_loss)
+        assert float((stepper.grads - want).abs().max()) <= 2e-5 * float(want.abs().max()), k     # atomics' order only
+    assert not torch.equal(seen[0][1], seen[1][1]) and not torch.equal(seen[1][1], seen[2][1])    # fresh positions per step
+    ts = seen[0][1]
+    edges = torch.linspace(2, 6, N + 1).to(dev)
+    assert bool((ts >= edges[:-1]).all()) and bool((ts <= edges[1:]).all())                        # stratified: one per bin
+    other = GraphedTrainStep(fresh_net := fresh(), FusedAdam(fresh_net, lr=0.0), B, N, device_rng=True, seed=40, ray_id0=0)
+    other.step(rays, gt)
+    torch.cuda.synchronize()
+    assert not torch.equal(other.ts, seen[0][1])
