@@ -201,28 +201,37 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
     const int brow = tid & 15, bchunk = tid >> 4;
     const unsigned baddr = bchunk * 256 + ((brow ^ ((bchunk & 3) << 2)) * 16);
 
-    // prologue: up to RING-1 slabs in flight
+    // prologue: up to RING-1 slabs in flight; slab 0 published, its first fragments requested
 #pragma unroll
     for (int k = 0; k < RING - 1; ++k)
         if (s_begin + k < s_end) issue_slab(k, k);
+    // The slab loop is software-pipelined across slabs.  A slab's barrier -- "everyone's pieces of slab s+1 have landed,
+    // everyone is past slab s-1" -- sits in the MIDDLE of slab s, behind the eight MFMAs of its first k-step, and the
+    // first fragments of slab s+1 are requested right behind the second k-step's fragments have landed: the barrier
+    // wait and the LDS round trip of every slab's first reads are covered by matrix work of the same wave instead of
+    // standing at the head of each slab (the early-barrier idea of mlp_bf16_16.hip).  Fragment registers: a0/b0 are
+    // free once the first k-step's MFMAs are issued, so the next slab's first fragments reuse them.
+    Frag a0[4], b0[2], a1[4], b1[2];
+    auto read_k0 = [&](unsigned base) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) read_frag_tr<0>(a0[i], base + aoff[i][0], base + aoff[i][1]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) read_frag_tr<0>(b0[j], base + boff[j][0], base + boff[j][1]);
+    };
+    if (s_begin < s_end) {
+        const long long n = s_end - s_begin;
+        if (n >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (n == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();              // everyone's pieces of slab 0 landed
+        if (active) read_k0(0);
+    }
     for (long long s = s_begin; s < s_end; ++s) {
         const int it = (int)(s - s_begin), slot = it & (RING - 1);
-        // this wave's pieces of slab s have landed once at most the DMAs of the (up to) two newer slabs remain
         const long long left = s_end - s;
-        if (left >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (left == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();              // everyone's pieces landed; everyone is done with slab s-1
-        if (s + RING - 1 < s_end) issue_slab(it + RING - 1, (it + RING - 1) & (RING - 1));
         const unsigned base = slot * SLOTB;
         if (active) {
-            // two k-steps per slab: the second step's fragments are read under the first step's MFMAs
-            Frag a0[4], b0[2], a1[4], b1[2];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) read_frag_tr<0>(a0[i], base + aoff[i][0], base + aoff[i][1]);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) read_frag_tr<0>(b0[j], base + boff[j][0], base + boff[j][1]);
-            frags_landed(a0, b0);
+            frags_landed(a0, b0);                  // slab s, first k-step (requested half a slab ago)
 #pragma unroll
             for (int i = 0; i < 4; ++i) read_frag_tr<KSTEP>(a1[i], base + aoff[i][0], base + aoff[i][1]);
 #pragma unroll
@@ -234,7 +243,18 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_kernel(GemmTable tab) {
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(whole(a0[i]), whole(b0[j]), acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (left >= 2) {
+            // this wave's pieces of slab s+1 have landed once at most the DMAs of slab s+2 remain (s+3 is not issued yet)
+            if (left >= 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // slab s+1 published; everyone is done with slab s-1 (and its column sums)
+            if (s + RING - 1 < s_end) issue_slab(it + RING - 1, (it + RING - 1) & (RING - 1));    // into the slot of slab s-1
+        }
+        if (active) {
             frags_landed(a1, b1);
+            if (left >= 2) read_k0(((it + 1) & (RING - 1)) * SLOTB);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
