@@ -147,3 +147,22 @@ def test_bench_rccl_single_rank_rehearsal(mode):
         assert res["collective_ms"] >= res["collective_exposed_ms"] >= 0 and np.isfinite(res["final_loss"])
     print(f"RCCL single-rank rehearsal, {mode}: {res['ms_per_step']:.3f} ms/step, collective {res['collective_ms']:.4f} ms"
           + (f" (exposed {res['collective_exposed_ms']:.4f})" if mode == "train" else ""))
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's own launch line for N > 1 -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` -- rehearsed with two ranks on the one GPU over gloo:
+    the ranks take RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (no self-launch), and exactly one JSON
+    line reaches stdout."""
+    env = dict(os.environ, NERF_BENCH_BACKEND="gloo", NERF_BENCH_SHARE_GPU="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines[:5]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["ranks"]["world_size"] == 2 and res["scaling"] == "strong"
+    assert "cpu_baseline" not in res and "aux" not in res           # N = 1 only
