@@ -370,3 +370,40 @@ def test_non_finite_inputs_propagate_like_the_reference(dev, oracle, synthetic, 
         assert np.array_equal(np.isnan(a), np.isnan(b)), (precision, name)
         ok = ~np.isnan(b)
         assert np.abs(a[ok] - b[ok]).max() <= 1e-4 * max(1.0, np.abs(b[ok]).max()), (precision, name)   # it IS the fp32 kernel by now
+
+
+def test_render_beyond_two_to_the_31_samples(dev, synthetic):
+    """A batch whose sample count does not fit 32 bits: 17,000,000 rays x 128 samples = 2.176e9 ray-samples in ONE call
+    (the C ABI's sizes are int64).  Every index on the path -- point ids, the counter RNG's sample counter, per-workgroup
+    ray ranges, output offsets -- has to be 64-bit where it can grow: the last rays of the batch, and rays around the
+    2^31-sample mark, must come out exactly as when they are rendered on their own with the matching ray-id offset."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.xyz import camera_rays, spherical_to_pose
+    lib = _lib.lib()
+    net = Nerf(precision="bf16").to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "structured"))
+    packed = net.packed_weights(_lib.BF16)
+    pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
+    base = camera_rays([pose], [1000, 1000, synthetic.focal_from_fov(1000)]).to(dev)          # 1 M distinct rays
+    B, N = 17_000_000, 128
+    assert B * N > 2 ** 31
+    rays = base.repeat(17, 1).contiguous()
+    tb = torch.linspace(2, 6, N + 1).to(dev)
+    px = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    st = _lib.stream_ptr(dev)
+    _lib.check(lib.nerf_amd_render_pixels_forward(_lib.ptr(rays), None, _lib.ptr(tb), _lib.ptr(packed), _lib.BF16,
+                                                  _lib.FLAG_DEVICE_RNG, 99, 0, _lib.ptr(px), None, B, N, st), "render")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(px[:, :3]).all())
+    mark = 2 ** 31 // N                                         # the ray whose first sample is sample 2^31
+    for lo in (0, mark - 500, mark + 1, B - 1000):
+        part = rays[lo:lo + 1000].contiguous()
+        small = torch.empty((1000, 4), dtype=torch.float32, device=dev)
+        _lib.check(lib.nerf_amd_render_pixels_forward(_lib.ptr(part), None, _lib.ptr(tb), _lib.ptr(packed), _lib.BF16,
+                                                      _lib.FLAG_DEVICE_RNG, 99, lo, _lib.ptr(small), None, 1000, N, st), "render")
+        torch.cuda.synchronize()
+        a, b = px[lo:lo + 1000], small
+        assert bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all()), lo
+    # the same scene ray under another ray id draws other jitter: the 17 copies of the table are not copies of pixels
+    assert not torch.equal(px[:1000, :3], px[1_000_000:1_001_000, :3])
