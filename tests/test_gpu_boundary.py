@@ -407,3 +407,52 @@ def test_render_beyond_two_to_the_31_samples(dev, synthetic):
         assert bool(((a == b) | (torch.isnan(a) & torch.isnan(b))).all()), lo
     # the same scene ray under another ray id draws other jitter: the 17 copies of the table are not copies of pixels
     assert not torch.equal(px[:1000, :3], px[1_000_000:1_001_000, :3])
+
+
+def test_integration_training_stub_from_the_document(dev, golden, synthetic):
+    """INTEGRATION.md's second code block -- the training step of train.py:47-57 unrolled over the C ABI -- run as
+    printed on golden G6: loss and every gradient norm the reference's autograd produced, within the bf16 training
+    bounds of tests/test_gpu_training.py."""
+    import os
+    import re
+    import sys
+    import types
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.nets import Nerf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    first = re.search(r"```python\n(# utils/_nerf_amd\.py.*?)```", text, flags=re.S).group(1)
+    second = re.search(r"```python\n(# utils/_nerf_amd_train\.py.*?)```", text, flags=re.S).group(1)
+    first = first.replace('ctypes.CDLL("libnerf_amd.so")', f'ctypes.CDLL("{_lib.LIB_PATH}")')
+    base = types.ModuleType("utils._nerf_amd")
+    exec(compile(first, "INTEGRATION.md:stub", "exec"), base.__dict__)
+    pkg = types.ModuleType("utils")
+    saved = {k: sys.modules.get(k) for k in ("utils", "utils._nerf_amd")}
+    sys.modules["utils"], sys.modules["utils._nerf_amd"] = pkg, base
+    try:
+        ns = {}
+        exec(compile(second, "INTEGRATION.md:train stub", "exec"), ns)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    g = golden("train.npz")
+    net = Nerf(precision="bf16").to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+    images = ns["pack_for_training"](net)
+    saved_rng = torch.get_rng_state()
+    try:
+        torch.manual_seed(66)                                 # G6's seed: the stub draws torch.rand(B, N) like the reference
+        loss, grads = ns["loss_and_gradients"](t(g["rays"]).to(dev), t(g["gt"]).to(dev), images, int(g["N"]))
+    finally:
+        torch.set_rng_state(saved_rng)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(g["loss"])) <= 1e-3 * float(g["loss"])
+    off = 0
+    for k, shape in synthetic.PARAM_SPECS:
+        n = int(np.prod(shape))
+        got = grads[off:off + n].cpu().numpy()
+        off += n
+        assert abs(np.linalg.norm(got) / float(g[f"gnorm/{k}"]) - 1) <= 8.4e-2, k      # rel_l2_bound("default", 4096)
