@@ -65,7 +65,7 @@ PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: 80 (render) / 4000 (train): >= 5 s of GPU time")
+    ap.add_argument("--steps", type=int, default=None, help="default: 150 (render) / 6000 (train): 7-10 s of GPU time")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--mode", default="render", choices=["render", "train"])
     ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
@@ -76,7 +76,7 @@ def parse():
                     help="rays of the CPU-baseline sample (x128 samples; the reference's test batch)")
     a = ap.parse_args()
     if a.steps is None:
-        a.steps = 80 if a.mode == "render" else 4000
+        a.steps = 150 if a.mode == "render" else 6000
     if a.warmup is None:
         a.warmup = 5 if a.mode == "render" else 50
     return a
