@@ -61,7 +61,8 @@ int64_t  nerf_amd_packed_bytes(int precision);
  * block of sticky uint32 flags (0 / 1), zeroed by nerf_amd_pack_weights:
  *   word NERF_AMD_STATUS_WORD_NONFINITE     set by every 16-bit MLP forward kernel when a point's (rgb, sigma) output
  *                                           is inf or NaN (where an overflowed hidden activation ends up);
- *   word NERF_AMD_STATUS_WORD_WEIGHT_RANGE  set by the packer if a finite weight is not finite in the operand type.
+ *   word NERF_AMD_STATUS_WORD_WEIGHT_RANGE  set by the packer if a weight is not finite in the operand type (beyond its
+ *                                           range, or NaN / inf to begin with).
  * Returns the byte offset of word 0 inside the image, -1 for images without a status block (NERF_AMD_F32,
  * NERF_AMD_BF16_BWD).  The host wrapper (utils/nets.py) reads it after the first fp16 render of a weight set and
  * falls back to bf16 operands with a warning instead of returning NaN pixels. */
@@ -87,7 +88,10 @@ int      nerf_amd_layout_src_col(int precision, int layer, int kstep, int group,
  * the MFMA-fragment-ordered image the fused kernels stream.  Derived cache:
  * re-run after any parameter update.  */
 int nerf_amd_pack_weights(const float* params, void* packed, int precision, void* stream);
-/* The two images a training step needs (NERF_AMD_BF16 and NERF_AMD_BF16_BWD) in one launch. */
+/* The two images a training step needs (NERF_AMD_BF16 and NERF_AMD_BF16_BWD) in one launch.  Clears the status block of
+ * the forward image except NERF_AMD_STATUS_WORD_WEIGHT_RANGE, which it only ever sets (a non-finite weight stays
+ * non-finite under Adam; nerf_amd_pack_weights clears the word): `packed_bf16` is an image that nerf_amd_pack_weights
+ * has filled before (any weights), re-packed in place from then on. */
 int nerf_amd_pack_weights_train(const float* params, void* packed_bf16, void* packed_bwd, void* stream);
 
 /* ---- positional encoding: utils/xyz.py:6-36 --------------------------------- */

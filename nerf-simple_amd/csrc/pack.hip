@@ -23,10 +23,10 @@ __global__ void pack_b16_kernel(const float* __restrict__ params, T* __restrict_
         const float wv = weight_at(params, L, row, src_col_b16(L, s, g, j));
         const T cv = (T)wv;
         out[e] = cv;
-        // a finite weight that is not finite in the operand type (fp16: |w| > 65504): sticky flag (the status word
-        // was zeroed by pack_bias_kernel, launched in front of this kernel)
-        if (__builtin_fabsf(wv) < __builtin_inff() && !(__builtin_fabsf((float)cv) < __builtin_inff()))
-            status[NERF_STATUS_WORD_WEIGHT_RANGE] = 1u;
+        // a weight that is not finite in the operand type -- beyond its range (fp16: |w| > 65504), or NaN / inf to
+        // begin with (a diverged run): sticky flag (the status block was zeroed by pack_bias_kernel, launched in front
+        // of this kernel)
+        if (!(__builtin_fabsf((float)cv) < __builtin_inff())) status[NERF_STATUS_WORD_WEIGHT_RANGE] = 1u;
     }
 }
 
@@ -81,10 +81,15 @@ __global__ void pack_bias_kernel(const float* __restrict__ params, float* __rest
     }
 }
 
-// the three images of a training step in ONE launch: forward bf16 image, its bias table, backward image
+// the three images of a training step in ONE launch: forward bf16 image, its bias table, backward image.  The status
+// block is cleared here EXCEPT the weight-range word: that one is set by whichever workgroup meets the weight, and a
+// clear from another workgroup in the same kernel would land in no defined order (two XCDs' L2s writing one word).  It
+// therefore stays set from one training step to the next -- which is also what the weights do: Adam never heals a NaN /
+// inf weight -- until nerf_amd_pack_weights (new weights) clears it.
 __global__ void pack_train_kernel(const float* __restrict__ params, __bf16* __restrict__ img, float* __restrict__ bias,
                                   __bf16* __restrict__ bwd, unsigned* __restrict__ status) {
-    if (blockIdx.x == 0 && threadIdx.x < B16_STATUS_BYTES / 4) status[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < B16_STATUS_BYTES / 4 && threadIdx.x != NERF_STATUS_WORD_WEIGHT_RANGE)
+        status[threadIdx.x] = 0u;
     const long long n_img = (long long)B16_WEIGHT_KIB * 512, n_bwd = (long long)BWD_WEIGHT_KIB * 512;
     const long long total = n_img + n_bwd + F32_BIAS_FLOATS;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
@@ -96,7 +101,9 @@ __global__ void pack_train_kernel(const float* __restrict__ params, __bf16* __re
             const int rel = kib - b16_layer_off_kib(L);
             const int rt = rel / b16_ks(L), s = rel % b16_ks(L);
             const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
-            img[e] = (__bf16)weight_at(params, L, 16 * rt + (lane & 15), src_col_b16(L, s, lane >> 4, j));
+            const __bf16 cv = (__bf16)weight_at(params, L, 16 * rt + (lane & 15), src_col_b16(L, s, lane >> 4, j));
+            img[e] = cv;
+            if (!(__builtin_fabsf((float)cv) < __builtin_inff())) status[NERF_STATUS_WORD_WEIGHT_RANGE] = 1u;   // as pack_b16_kernel
         } else if (e < n_img + n_bwd) {
             const long long q = e - n_img;
             const int kib = (int)(q >> 9);

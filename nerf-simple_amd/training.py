@@ -308,6 +308,40 @@ class _HyperRing:
         self.events[i] = ev
 
 
+class _StatusWatch:
+    """Asynchronous read-back of the status words behind a packed 16-bit weight image (include/nerf_amd.h
+    nerf_amd_packed_status_offset): the training forward sets word 0 when a point shows a non-finite value inside the
+    network, the re-pack of every step sets word 1 when a weight is not finite.  In the reference such a step ends in a NaN loss for everyone to see; here the kernels' integer ReLU can
+    turn the NaNs into finite garbage, so the flag is what makes a diverged run loud.  ``push`` enqueues an 8-byte copy
+    into pinned memory behind the forward, ``poll`` looks at the copies that have completed -- no host wait."""
+
+    def __init__(self, slots=4):
+        self.bufs = [torch.zeros(2, dtype=torch.int32).pin_memory() for _ in range(slots)]
+        self.pending = []                       # (event, slot, step)
+        self.k = 0
+
+    def push(self, packed, step):
+        if len(self.pending) >= len(self.bufs):
+            return                              # every slot still in flight: skip this sample
+        slot = self.k % len(self.bufs)
+        self.k += 1
+        off = int(_lib.lib().nerf_amd_packed_status_offset(_lib.BF16))
+        self.bufs[slot].copy_(packed[off:off + 8].view(torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(packed.device))
+        self.pending.append((ev, slot, step))
+
+    def poll(self):
+        """The first completed sample with a flag set, as (step, activations flagged, weights flagged), or None."""
+        hit = None
+        while self.pending and self.pending[0][0].query():
+            _, slot, step = self.pending.pop(0)
+            words = (int(self.bufs[slot][0]), int(self.bufs[slot][1]))
+            if hit is None and (words[0] != 0 or words[1] != 0):
+                hit = (step, words[0] != 0, words[1] != 0)
+        return hit
+
+
 class GraphedTrainStep:
     """``train_step`` (reference train.py:47-57) for the fused bf16 path with every buffer
     allocated once and the launches captured into hipGraphs that are replayed per iteration:
@@ -348,10 +382,14 @@ class GraphedTrainStep:
     eager ``train_step(..., device_rng=True, seed=seed + k, ray_id0=ray_id0)`` at step k (1-based).
 
     ``step(rays, gt, u=None, decay=1.0)`` returns the loss as a 0-d device tensor (no sync).
+
+    ``check_every`` (default 16, 0 = never): every so many steps the forward's range flag is copied back without
+    waiting; a later ``step`` raises FloatingPointError once such a copy shows non-finite values inside the network
+    (NaN / inf weights or inputs: a diverged run) -- the reference would show a NaN loss there.
     """
 
     def __init__(self, net, optimizer, n_rays, N, *, tn=2, tf=6, group=None, timing=False, buckets=1,
-                 device_rng=False, seed=0, ray_id0=0):
+                 device_rng=False, seed=0, ray_id0=0, check_every=16):
         from . import parallel
         from .optim import FusedAdam
         from .utils.rendering import _tbins
@@ -367,6 +405,7 @@ class GraphedTrainStep:
         self.bucketed = self.exchange and buckets == 2
         self.timing, self._events = bool(timing), []
         self.device_rng, self.seed, self.ray_id0 = bool(device_rng), int(seed), int(ray_id0)
+        self.check_every, self._watch = int(check_every), _StatusWatch()
         self.B, self.N = int(n_rays), int(N)
         dev = optimizer.flat.device
         self.dev = dev
@@ -374,6 +413,7 @@ class GraphedTrainStep:
         B, N_, P = self.B, self.N, self.B * self.N
         f32 = dict(dtype=torch.float32, device=dev)
         self.rays = torch.zeros((B, 6), **f32)
+        self.rays[:, 5] = -1.0                      # a valid direction: the capture warm-up runs on these buffers
         self.gt = torch.zeros((B, 3), **f32)
         self.u = torch.zeros((B, N_), **f32)
         self.tbins = _tbins(tn, tf, N_, dev)
@@ -496,12 +536,19 @@ class GraphedTrainStep:
                 self._update()
             # capture executed nothing, and the warm-up did not touch the parameters
             assert torch.equal(self.opt.flat, params0)
+            # a fresh pair of training images: whatever the warm-up left in their status words is gone
+            self.net.repack_from_flat(self.opt.flat)
 
     # ---- one iteration -------------------------------------------------------------
     def step(self, rays, gt, u=None, decay=1.0):
         from . import parallel
         if rays.shape != self.rays.shape or gt.shape != self.gt.shape:
             raise RuntimeError(f"GraphedTrainStep was captured for rays {tuple(self.rays.shape)}, gt {tuple(self.gt.shape)}")
+        bad = self._watch.poll()
+        if bad is not None:
+            what = " and ".join(w for w, on in (("activations", bad[1]), ("weights", bad[2])) if on)
+            raise FloatingPointError(f"non-finite values inside the network in training step {bad[0]} ({what}): "
+                                     "NaN / inf weights or inputs, the run has diverged")
         self.rays.copy_(rays, non_blocking=True)
         self.gt.copy_(gt, non_blocking=True)
         if self.device_rng:
@@ -517,6 +564,9 @@ class GraphedTrainStep:
         self.opt.step_count += 1
         self._set_hyper(self.opt.step_count)
         self.graph_a.replay()
+        if self.check_every and self.opt.step_count % self.check_every == 0:
+            # behind the forward, in front of graph B's re-pack (which clears the flag for the next step)
+            self._watch.push(self.net.packed_weights(_lib.BF16), self.opt.step_count)
         if self.bucketed:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.timing else None
             if ev:

@@ -203,7 +203,7 @@ class Nerf(nn.Module):
         entry.demoted = True
         why = []
         if flags & _lib.STATUS_WEIGHT_RANGE:
-            why.append("a weight beyond 65504")
+            why.append("a weight beyond 65504" if code == _lib.FP16 else "a weight that is not finite")
         if flags & _lib.STATUS_NONFINITE:
             why.append(f"a non-finite value inside the network in {where}")
         if code == _lib.FP16:

@@ -140,6 +140,10 @@ def test_fused_train_compositor_and_pack(dev, synthetic):
     a1 = torch.zeros(int(lib.nerf_amd_packed_bytes(_lib.BF16)), dtype=torch.uint8, device=dev)
     b1 = torch.zeros(int(lib.nerf_amd_packed_bytes(_lib.BF16_BWD)), dtype=torch.uint8, device=dev)
     a2, b2 = torch.ones_like(a1), torch.ones_like(b1)
+    # the one-launch form re-packs an image that nerf_amd_pack_weights has initialised (it never clears the sticky
+    # weight-range word): start from the image of OTHER weights, as a training step does
+    other = synthetic.flatten_state_dict(synthetic.synthetic_state_dict(4, "default")).to(dev)
+    _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(other), _lib.ptr(a2), _lib.BF16, st), "p")
     _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(flat), _lib.ptr(a1), _lib.BF16, st), "p")
     _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(flat), _lib.ptr(b1), _lib.BF16_BWD, st), "p")
     _lib.check(lib.nerf_amd_pack_weights_train(_lib.ptr(flat), _lib.ptr(a2), _lib.ptr(b2), st), "p")
@@ -657,3 +661,29 @@ def test_graphed_step_with_device_jitter(dev, golden, synthetic):
     other.step(rays, gt)
     torch.cuda.synchronize()
     assert not torch.equal(other.ts, seen[0][1])
+
+
+def test_diverged_training_is_loud(dev, golden, synthetic):
+    """A NaN that reaches the weights (a diverged run): the reference's loss turns NaN.  The kernels' integer ReLU can
+    turn NaNs into finite garbage instead, so GraphedTrainStep watches the forward's range flag: a later step raises
+    FloatingPointError.  A healthy run never trips it."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.optim import FusedAdam
+    from nerf_simple_amd.training import GraphedTrainStep
+    g = golden("train.npz")
+    rays, gt, u, N = t(g["rays"]).to(dev), t(g["gt"]).to(dev), t(g["u"]).to(dev), int(g["N"])
+    net = Nerf(precision="bf16").to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+    opt = FusedAdam(net, lr=5e-4)
+    stepper = GraphedTrainStep(net, opt, rays.shape[0], N, check_every=1)
+    for _ in range(5):
+        stepper.step(rays, gt, u=u)
+    torch.cuda.synchronize()
+    stepper.step(rays, gt, u=u)                               # healthy: nothing raised
+    with torch.no_grad():
+        opt.flat[70000] = float("nan")                        # one weight of layers_0.2 goes bad behind everyone's back
+    net.repack_from_flat(opt.flat)
+    with pytest.raises(FloatingPointError, match="non-finite values inside the network"):
+        for _ in range(4):
+            stepper.step(rays, gt, u=u)
+            torch.cuda.synchronize()
