@@ -891,3 +891,71 @@ def test_render_hierarchical_view_equals_composition(dev, oracle, synthetic, pre
     # the sampler's limits (Nc <= 256, Nc + Nf <= 512) come back as "unsupported", not as a wrong image
     with pytest.raises(RuntimeError, match="unsupported"):
         render_hierarchical_view(nc, nf, pose, cam, 300, 100, device_rng=True)
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
+def test_headline_workload_properties(dev, synthetic, oracle, precision):
+    """The benched workload itself (BASELINE config 3: one 800 x 800 view, 128 samples per ray, one launch) -- too big
+    for the CPU oracle, so: size-independent properties over the whole image, and the oracle on a scatter of its rays.
+      * the one-launch view == the reference's batched loop over the same rays (16000-ray batches as in
+        utils/rendering.py:139-151), bit for bit, all 640000 pixels: no pixel depends on the launch geometry
+        (workgroup ray ranges, ring wrap-around, tile boundaries inside rays);
+      * 96 rays scattered over the image, each rendered ALONE (a 128-point launch), reproduce their pixels of the big
+        launch bit for bit: global ray ids key the jitter, nothing else leaks in from the neighbours;
+      * the same rays through the CPU oracle with the jitter the kernel drew (recovered from the sample positions):
+        inside the 16-bit tolerance of the golden tests;
+      * rgb in [0, 1] after the view driver's clip, finite disparity wherever a ray hit anything."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.rendering import generate_rays, render_nerf, render_view
+    from nerf_simple_amd.utils.xyz import spherical_to_pose
+    H = W = 800
+    N, SEED = 128, 11
+    net = make_net(synthetic, dev, "structured", precision)
+    pose = spherical_to_pose(4, -30, 0)
+    cam = [H, W, synthetic.focal_from_fov(W)]
+    with torch.no_grad():
+        view = render_view(net, pose, cam, N=N, device_rng=True, seed=SEED)
+        rays = generate_rays(pose, cam, dev)
+        rgb_b, disp_b = [], []
+        for s in range(0, H * W, 16000):
+            rgb, disp, _, _, _ = render_nerf(rays[s:s + 16000], net, N, device_rng=True, seed=SEED, ray_id0=s,
+                                             outputs=("rgb", "disp"))
+            rgb_b.append(rgb)
+            disp_b.append(disp)
+        rgb_b, disp_b = torch.cat(rgb_b), torch.cat(disp_b)
+    assert view.shape == (H * W, 4)
+    assert torch.equal(view[:, :3], rgb_b.clamp(0, 1))
+    assert torch.equal(torch.nan_to_num(view[:, 3], nan=-1.0), torch.nan_to_num(disp_b, nan=-1.0))
+    assert float(view[:, :3].min()) >= 0 and float(view[:, :3].max()) <= 1
+    assert float(view[:, :3].std()) > 0.05                       # an image, not a constant
+
+    gen = torch.Generator().manual_seed(5)
+    picks = torch.cat([torch.tensor([0, W - 1, H * W - W, H * W - 1, 2499, 2500, 2501]),   # corners, a workgroup seam
+                       torch.randint(0, H * W, (89,), generator=gen)]).tolist()
+    lib = _lib.lib()
+    tb = torch.linspace(2, 6, N + 1).to(dev)
+    tol = TOL[(precision, "structured")]
+    sd = synthetic.synthetic_state_dict(0, "structured")
+    for r in picks:
+        one = rays[r:r + 1].contiguous()
+        with torch.no_grad():
+            rgb, disp, _, acc, _ = render_nerf(one, net, N, device_rng=True, seed=SEED, ray_id0=r)
+        assert torch.equal(rgb.clamp(0, 1)[0], view[r, :3]), r
+        assert torch.equal(torch.nan_to_num(disp, nan=-1.0)[0], torch.nan_to_num(view[r, 3:4], nan=-1.0)[0]), r
+    # the oracle on 24 of them, with the jitter the kernel drew
+    sub = picks[:24]
+    sel = rays[sub].contiguous()
+    us = []
+    for i, r in enumerate(sub):
+        raw = torch.empty(1, N, 4, device=dev)
+        ts = torch.empty(1, N, device=dev)
+        _lib.check(lib.nerf_amd_mlp_forward_rays(_lib.ptr(sel[i:i + 1]), None, _lib.ptr(tb), _lib.ptr(net.packed_weights()),
+                                                 _lib.precision_code(precision), _lib.FLAG_DEVICE_RNG, SEED, r,
+                                                 _lib.ptr(raw), _lib.ptr(ts), 1, N, _lib.stream_ptr(dev)), "ts")
+        us.append(ts.cpu())
+    ts_all = torch.cat(us)
+    with torch.no_grad():
+        want = oracle.render_nerf(sel.cpu(), sd, N, ts=ts_all)
+    got = view[sub].cpu().numpy()
+    worst = scaled_err(got[:, :3], want[0].clamp(0, 1).numpy())
+    assert worst <= tol, worst
