@@ -354,6 +354,23 @@ int nerf_amd_mt19937_uniform_par(const uint32_t* state624, int next, float* out,
 int nerf_amd_adam_step_hyper(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                              int64_t n, const float* hyper, void* stream);
 
+/* ---- networks of other sizes: Nerf(Lp, Ld, H), reference utils/nets.py:9-32 ---------------- */
+/* The fused kernels implement the one configuration the reference constructs (Nerf() = (10, 4, 256): train.py:41,
+ * test.py:27).  Every nn.Linear (+ nn.ReLU) of any other size, and its backward (dX = dY W, dW = dY^T X, db = dY^T 1),
+ * is this strided fp32 GEMM on the exact-f32 MFMA:
+ *     C[i*ldc + j] (+)= sum_k A(i,k) * B(k,j) (+ bias[j]) (ReLU),   i < M, j < N, k < K
+ *     A(i,k) = A[i*sa_i + k*sa_k], taken as 0 where A_mask[i*sa_i + k*sa_k] <= 0 (A_mask may be NULL: the ReLU
+ *              derivative of a saved activation applied to the incoming gradient);
+ *     B(k,j) = B[k*sb_k + j*sb_j] (a weight matrix or a column slice of one, an activation, or one 1.0f with both
+ *              strides 0 for column sums).
+ * flags: NERF_AMD_LINEAR_RELU, NERF_AMD_LINEAR_ACCUMULATE (C += ; with a long K and few output tiles the reduction is
+ * split and summed with float atomics: summation order then varies from run to run).  bias may be NULL. */
+#define NERF_AMD_LINEAR_RELU       1u
+#define NERF_AMD_LINEAR_ACCUMULATE 2u
+int nerf_amd_linear_f32(const float* A, int64_t sa_i, int64_t sa_k, const float* A_mask,
+                        const float* B, int64_t sb_k, int64_t sb_j, const float* bias,
+                        float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, uint32_t flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

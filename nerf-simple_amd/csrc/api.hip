@@ -36,6 +36,8 @@ int nerf_amd_launch_mt19937_uniform(const uint32_t*, int, float*, long long, uin
 int nerf_amd_launch_mt19937_uniform_par(const uint32_t*, int, float*, long long, uint32_t*, const uint32_t*, int, long long,
                                         uint32_t*, hipStream_t);
 int nerf_amd_launch_adam_hyper(float*, const float*, float*, float*, long long, const float*, hipStream_t);
+int nerf_amd_launch_linear_f32(const float*, long long, long long, const float*, const float*, long long, long long, const float*,
+                               float*, long long, long long, long long, long long, int, hipStream_t);
 int nerf_amd_launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float, float,
                          hipStream_t);
 int nerf_amd_launch_sample_encode_bf16(const MlpArgs*, void*, void*, hipStream_t);
@@ -537,6 +539,15 @@ int nerf_amd_mt19937_uniform_par(const uint32_t* state624, int next, float* out,
     if (nseg > ((int64_t)1 << levels)) return NERF_AMD_EUNSUP;
     return nerf_amd_launch_mt19937_uniform_par(state624, next, out, n, state_out624, polys, levels, seg_words, seg_states,
                                                S(stream));
+}
+
+int nerf_amd_linear_f32(const float* A, int64_t sa_i, int64_t sa_k, const float* A_mask, const float* B, int64_t sb_k,
+                        int64_t sb_j, const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, uint32_t flags,
+                        void* stream) {
+    if (M < 0 || N < 0 || K < 0 || (flags & ~3u)) return NERF_AMD_EINVAL;
+    if (M == 0 || N == 0) return 0;
+    if (!C || ldc < N || (K > 0 && (!A || !B))) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_linear_f32(A, sa_i, sa_k, A_mask, B, sb_k, sb_j, bias, C, ldc, M, N, K, (int)flags, S(stream));
 }
 
 int nerf_amd_adam_step_hyper(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

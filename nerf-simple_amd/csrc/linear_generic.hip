@@ -1,0 +1,140 @@
+// linear_generic.hip -- one strided fp32 GEMM on v_mfma_f32_16x16x4_f32 for the networks the fused kernels are NOT
+// built for: the reference's Nerf(Lp, Ld, H) takes any sizes (utils/nets.py:9-32), the fused kernels implement the one
+// it ever constructs (Nerf() = (10, 4, 256), train.py:41, test.py:27).  Every nn.Linear of such a network -- forward
+// (y = x W^T + b, optional ReLU), and in the backward dX = dY W, dW = dY^T X, db = dY^T 1 -- is this kernel with other
+// strides (utils/generic_mlp.py lists the calls):
+//
+//     C[i, j]  (+)=  sum_k  A(i, k) * B(k, j)  (+ bias[j])  (ReLU)          i < M, j < N, k < K
+//     A(i, k) = A[i * sa_i + k * sa_k]   -- or 0 where A_mask[i * sa_i + k * sa_k] <= 0 (the ReLU derivative of a
+//                                           saved activation, applied to the incoming gradient on the fly)
+//     B(k, j) = B[k * sb_k + j * sb_j]   -- a weight matrix, a slice of one (concatenated inputs), a saved activation,
+//                                           or a single 1.0f with both strides 0 (column sums = bias gradients)
+//
+// Exact fp32 products and fp32 accumulation (the MFMA is an fma chain); a correct, tidy kernel rather than a tuned
+// one: 64 x 64 output tile per workgroup of four waves, K in steps of 16 through LDS, loads coalesced along whichever
+// index is contiguous.  Long reductions with few output tiles (dW: K = number of points) are split over blockIdx.z and
+// summed with float atomics.
+#include "nerf_device.h"
+
+namespace {
+
+constexpr int TM = 64, TN = 64, TK = 16;
+constexpr int LIN_RELU = 1, LIN_ACCUMULATE = 2;
+
+struct LinArgs {
+    const float* A;
+    long long sa_i, sa_k;
+    const float* A_mask;
+    const float* B;
+    long long sb_k, sb_j;
+    const float* bias;
+    float* C;
+    long long ldc;
+    long long M, N, K;
+    long long k_chunk;          // K range of one blockIdx.z
+    int flags;
+    int atomic;                 // split-K: add the partial sums atomically
+};
+
+__global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs a) {
+    __shared__ float As[TK][TM + 4];
+    __shared__ float Bs[TK][TN + 4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long long i0 = (long long)blockIdx.x * TM, j0 = (long long)blockIdx.y * TN;
+    const long long k_lo = (long long)blockIdx.z * a.k_chunk;
+    const long long k_hi = k_lo + a.k_chunk < a.K ? k_lo + a.k_chunk : a.K;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;      // this wave's 32 x 32 quarter of the tile
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool a_i_fast = a.sa_i == 1 && a.sa_k != 1;            // consecutive threads along the contiguous index
+    const bool b_j_fast = a.sb_j == 1 || a.sb_k != 1;
+    for (long long k0 = k_lo; k0 < k_hi; k0 += TK) {
+#pragma unroll
+        for (int r = 0; r < TM * TK / 256; ++r) {
+            const int e = tid + 256 * r;
+            const int i = a_i_fast ? e % TM : e / TK, k = a_i_fast ? e / TM : e % TK;
+            float v = 0.f;
+            if (i0 + i < a.M && k0 + k < k_hi) {
+                const long long off = (i0 + i) * a.sa_i + (k0 + k) * a.sa_k;
+                v = a.A[off];
+                if (a.A_mask && !(a.A_mask[off] > 0.f)) v = 0.f;
+            }
+            As[k][i] = v;
+        }
+#pragma unroll
+        for (int r = 0; r < TN * TK / 256; ++r) {
+            const int e = tid + 256 * r;
+            const int j = b_j_fast ? e % TN : e / TK, k = b_j_fast ? e / TN : e % TK;
+            float v = 0.f;
+            if (j0 + j < a.N && k0 + k < k_hi) v = a.B[(k0 + k) * a.sb_k + (j0 + j) * a.sb_j];
+            Bs[k][j] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < TK / 4; ++ks) {
+            const int kk = 4 * ks + (lane >> 4);
+            float af[2], bf[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                af[t] = As[kk][wi + 16 * t + (lane & 15)];
+                bf[t] = Bs[kk][wj + 16 * t + (lane & 15)];
+            }
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ti], bf[tj], acc[ti][tj], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[m = 4 * (lane / 16) + r][n = lane % 16] per 16 x 16 tile
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long i = i0 + wi + 16 * ti + 4 * (lane >> 4) + r, j = j0 + wj + 16 * tj + (lane & 15);
+                if (i >= a.M || j >= a.N) continue;
+                float* dst = a.C + i * a.ldc + j;
+                float v = acc[ti][tj][r];
+                if (a.atomic) {
+                    atomicAdd(dst, v);
+                    continue;
+                }
+                if (a.bias) v += a.bias[j];
+                if (a.flags & LIN_ACCUMULATE) v += *dst;
+                if (a.flags & LIN_RELU) v = v < 0.f ? 0.f : v;       // keeps NaN, as torch's relu does
+                *dst = v;
+            }
+}
+
+}  // namespace
+
+extern "C" int nerf_amd_launch_linear_f32(const float* A, long long sa_i, long long sa_k, const float* A_mask, const float* B,
+                                          long long sb_k, long long sb_j, const float* bias, float* C, long long ldc,
+                                          long long M, long long N, long long K, int flags, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (M <= 0 || N <= 0) return 0;
+    LinArgs a{A, sa_i, sa_k, A_mask, B, sb_k, sb_j, bias, C, ldc, M, N, K, K > 0 ? K : 1, flags, 0};
+    const long long gx = (M + TM - 1) / TM, gy = (N + TN - 1) / TN;
+    long long gz = 1;
+    // few output tiles and a long reduction (weight / bias gradients over all points): split K, sum with atomics
+    if ((flags & LIN_ACCUMULATE) && !(flags & LIN_RELU) && !bias && K >= 8192 && gx * gy < 1024) {
+        gz = (K + 4095) / 4096;
+        const long long want = 2048 / (gx * gy);
+        if (gz > want) gz = want;
+        if (gz < 1) gz = 1;
+    }
+    if (gz > 1) {
+        a.k_chunk = ((K + gz - 1) / gz + TK - 1) / TK * TK;
+        gz = (K + a.k_chunk - 1) / a.k_chunk;
+        a.atomic = 1;
+    }
+    if (gx > 2147483647ll || gy > 65535 || gz > 65535) return -1;
+    hipLaunchKernelGGL(linear_f32_kernel, dim3((unsigned)gx, (unsigned)gy, (unsigned)gz), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+}

@@ -118,6 +118,10 @@ class Nerf(nn.Module):
     forward(v): v [P,6] = [x,y,z,d1,d2,d3] -> [P,4] = [r,g,b,sigma], raw (no
     sigmoid on rgb; softplus on sigma is applied by the compositor).
 
+    Sizes other than the default (10, 4, 256) are accepted, as in the reference, and run layer by layer in fp32
+    (utils/generic_mlp.py: forward and backward on nerf_amd_linear_f32); everything below about `precision`, packed
+    weight images and the fused training kernels concerns the default shape.
+
     precision: 'fp16' (fp16 MFMA operands, fp32 accumulate; default: 11-bit mantissa,
                hidden activations must stay below 65504), 'bf16' (bf16 operands: same
                cycles, 5 % faster clock, 8-bit mantissa) or 'fp32' (exact-f32 MFMA).  Keyword-only
@@ -128,11 +132,12 @@ class Nerf(nn.Module):
 
     def __init__(self, Lp=10, Ld=4, H=256, *, precision=None):
         super().__init__()
-        if (Lp, Ld, H) != (10, 4, 256):
-            # the kernels are built for the one shape the reference ever constructs (Nerf() at train.py:41, test.py:27):
-            # refuse at construction rather than hand out a module whose forward cannot run
-            raise RuntimeError(f"Nerf(Lp={Lp}, Ld={Ld}, H={H}): unsupported configuration (NERF_AMD_EUNSUP) -- the HIP "
-                               "kernels implement Lp=10, Ld=4, H=256 only; utils.xyz.positional_encoder / gamma take any L")
+        if not all(isinstance(x, int) for x in (Lp, Ld, H)) or Lp < 1 or Ld < 1 or H < 2:
+            # (the reference's encoder concatenates an empty list at L = 0, utils/xyz.py:6-14; H // 2 = 0 has no colour head)
+            raise RuntimeError(f"Nerf(Lp={Lp}, Ld={Ld}, H={H}): sizes must be integers with Lp, Ld >= 1 and H >= 2")
+        # Nerf() = (10, 4, 256) -- the one shape the reference ever constructs (train.py:41, test.py:27) -- runs on the
+        # fused kernels; any other size runs layer by layer in fp32 on the strided GEMM kernel (utils/generic_mlp.py):
+        # same results as the reference module, `precision` has no effect there
         self.Lp, self.Ld, self.H = Lp, Ld, H
         self.precision = precision or DEFAULT_PRECISION
         _lib.precision_code(self.precision)
@@ -178,6 +183,9 @@ class Nerf(nn.Module):
 
     def _packed_entry(self, precision=None):
         code = _lib.precision_code(self.precision if precision is None else precision)
+        if not self._fused_ok():
+            raise RuntimeError(f"Nerf(Lp={self.Lp}, Ld={self.Ld}, H={self.H}) has no packed weight image (NERF_AMD_EUNSUP): "
+                               "the fused kernels implement (10, 4, 256); other sizes run through utils/generic_mlp.py")
         params = self._param_list()
         dev = params[0].device
         if dev.type != "cuda":
@@ -218,6 +226,8 @@ class Nerf(nn.Module):
         """Re-derive every packed image already in use from a flat fp32 parameter
         vector (state_dict order) whose views ARE this module's parameters
         (optim.FusedAdam): no per-tensor concatenation, cache stays valid."""
+        if not self._fused_ok():
+            return                                   # sizes on the layer-by-layer path read the parameters themselves
         lib = _lib.lib()
         dev = flat.device
         stamp = tuple((p.data_ptr(), p._version) for p in self._param_list())
@@ -251,12 +261,21 @@ class Nerf(nn.Module):
         _lib.require_cuda_f32(v, "v")
         if v.dim() != 2 or v.shape[1] != 6:
             raise RuntimeError("Nerf.forward expects a [P, 6] tensor")
+        if not self._fused_ok():
+            from . import generic_mlp
+            if torch.is_grad_enabled():
+                return generic_mlp.forward(self, v)
+            with torch.no_grad():
+                return generic_mlp.forward(self, v)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from ..training import nerf_forward_autograd
             return nerf_forward_autograd(self, v, self.precision if precision is None else precision)
         return self.forward_inference(v, precision=precision)
 
     def forward_inference(self, v, *, precision=None):
+        if not self._fused_ok():
+            with torch.no_grad():
+                return self.forward(v)
         code = _lib.precision_code(self.precision if precision is None else precision)
         v = v.detach().contiguous()
         P = v.shape[0]
@@ -278,6 +297,8 @@ class Nerf(nn.Module):
         around 1e-4 .. 1e-3); use precision='bf16' otherwise.  Diagnostic: runs the bf16 training forward
         once and scans the activations it saves (layers 0..9, post-ReLU / linear)."""
         _lib.require_cuda_f32(v, "v")
+        if not self._fused_ok():
+            return 0.0                               # fp32 throughout: no 16-bit range to leave
         lib = _lib.lib()
         v = v.detach().contiguous()
         P = v.shape[0]

@@ -241,16 +241,29 @@ def render_poses(net, poses, cam_params, batch_size, savepath='', *, N=128, tn=2
     the same table to the fma rounding of the 3-term rotation, 2.4e-7 absolute)."""
     H, W = cam_params[0], cam_params[1]
     dev = next(net.parameters()).device
-    rgb_imgs, disp_imgs = [], []
+    # The reference reads every image back as soon as it is rendered (:150-151, a blocking copy).  Here the copy of
+    # pose i runs on a side stream into pinned memory while pose i+1 renders; the arrays are handed out after the last
+    # copy has landed (the returned numpy arrays view that pinned memory).
+    copier = torch.cuda.Stream(device=dev)
+    rgb_host, disp_host = [], []
     for i in range(len(poses)):
         pose = poses[i].detach().cpu() if torch.is_tensor(poses[i]) else poses[i]
         rays = generate_rays(pose, cam_params, dev)
         ui = None if u is None else u[i * H * W:(i + 1) * H * W]
         rgb, disp = _render_batched(rays, net, batch_size, N, tn, tf, ui, progress,
                                     id_base=i * H * W, **kw)
-        rgb_imgs.append(rgb.cpu().reshape(H, W, 3).numpy())
-        disp_imgs.append(disp.cpu().reshape(H, W).numpy())
-    return rgb_imgs, disp_imgs
+        rgb_h = torch.empty((H, W, 3), dtype=torch.float32).pin_memory()
+        disp_h = torch.empty((H, W), dtype=torch.float32).pin_memory()
+        copier.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(copier):
+            rgb_h.copy_(rgb.view(H, W, 3), non_blocking=True)
+            disp_h.copy_(disp.view(H, W), non_blocking=True)
+        rgb.record_stream(copier)
+        disp.record_stream(copier)
+        rgb_host.append(rgb_h)
+        disp_host.append(disp_h)
+    copier.synchronize()
+    return [x.numpy() for x in rgb_host], [x.numpy() for x in disp_host]
 
 
 def render_rays_sharded(net, rays, batch_size, *, N=128, tn=2, tf=6, u=None, group=None, **kw):
@@ -302,6 +315,14 @@ def render_view(net, pose, cam_params, *, N=128, tn=2, tf=6, u=None, ray0=0, n_r
     dev = next(net.parameters()).device
     H, W, f = int(cam_params[0]), int(cam_params[1]), float(cam_params[2])
     n = H * W - ray0 if n_rays is None else int(n_rays)
+    if not (isinstance(net, Nerf) and net._fused_ok()):
+        # a net the fused kernels are not built for (another Nerf(Lp, Ld, H), any module with .forward): device ray
+        # generation, then the body of the reference's loop as it stands (render_nerf, clip)
+        rays = generate_rays(pose, cam_params, dev, ray0, n)
+        with torch.no_grad():
+            rgb, disp, _, _, _ = render_nerf(rays, net, N, tn, tf, u=u, outputs=("rgb", "disp", "acc"),
+                                             device_rng=device_rng, seed=seed, ray_id0=ray0)
+        return torch.cat([rgb.clamp(0., 1.), disp[:, None]], dim=1)
     code = _lib.precision_code(net.precision if precision is None else precision)
     net.packed_weights(code)
     flags, jit = 0, None

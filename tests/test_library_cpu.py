@@ -127,14 +127,30 @@ def test_state_dict_contract(synthetic):
     assert sum(p.numel() for p in net.parameters()) == 595844
 
 
-def test_unsupported_network_shapes_raise_at_construction():
-    """The kernels implement the one shape the reference constructs (Nerf() at train.py:41, test.py:27); any other
-    (Lp, Ld, H) is refused when the module is built, not when its forward first runs."""
+def test_network_sizes_follow_the_reference_constructor(oracle):
+    """Nerf(Lp, Ld, H) takes any sizes, as the reference's does (utils/nets.py:9-32): the same 24 state-dict keys with
+    the reference's shapes, loadable into the oracle's forward.  Sizes other than the default have no packed weight
+    image (they run on the layer-by-layer path, GPU tests) and say so; nonsense sizes raise at construction."""
+    import torch
     from nerf_simple_amd.utils.nets import Nerf
-    Nerf(10, 4, 256)
-    for args in ((6, 4, 256), (10, 2, 256), (10, 4, 128)):
-        with pytest.raises(RuntimeError, match="unsupported configuration"):
-            Nerf(*args)
+    assert Nerf(10, 4, 256)._fused_ok()
+    for Lp, Ld, H in ((6, 4, 256), (10, 2, 256), (10, 4, 128), (1, 1, 2), (3, 1, 40)):
+        net = Nerf(Lp, Ld, H)
+        assert not net._fused_ok()
+        sd = net.state_dict()
+        cx, cd = 3 + 6 * Lp, 3 + 6 * Ld
+        assert len(sd) == 24
+        assert sd["layers_0.0.weight"].shape == (H, cx) and sd["skip_conn_layer.0.weight"].shape == (H, H + cx)
+        assert sd["color_fc.0.weight"].shape == (H // 2, H + cd) and sd["color_fc.2.weight"].shape == (3, H // 2)
+        assert sd["sigma_fc.0.weight"].shape == (1, H)
+        with torch.no_grad():
+            out = oracle.nerf_forward(sd, torch.randn(5, 6), Lp, Ld)
+        assert out.shape == (5, 4)
+        with pytest.raises(RuntimeError, match="GPU|no packed weight image"):
+            net.packed_weights()
+    for bad in ((0, 4, 256), (10, 0, 256), (10, 4, 1), (10.5, 4, 256)):
+        with pytest.raises(RuntimeError, match="sizes must be integers"):
+            Nerf(*bad)
 
 
 def test_oracle_single_sample_is_the_reference_degenerate_case(oracle, synthetic):

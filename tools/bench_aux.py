@@ -55,6 +55,16 @@ with torch.no_grad():
         s = 800 * 800 * 128
         print(json.dumps({"config": "3: 800x800x128 fp16 via render_view (ray generation + the fused render kernel)", "ms": dt * 1e3,
                           "ray_samples_per_s": s / dt, "tflops": s * FLOP / dt / 1e12}))
+    if "poses" in which:   # the reference's video driver (utils/rendering.py:116-153): 6 poses, 16,000-ray batches, read-back included
+        from nerf_simple_amd.utils.rendering import render_poses
+        from nerf_simple_amd.utils.xyz import poses_to_render
+        net = net_of("fp16")
+        cam = [800, 800, synthetic.focal_from_fov(800)]
+        views = poses_to_render(4, -30, 6)
+        dt = timed(lambda: render_poses(net, views, cam, 16000, N=128, device_rng=True), warm=1, reps=2) / len(views)
+        s = 800 * 800 * 128
+        print(json.dumps({"config": "3 through render_poses: 6 poses of 800x800x128, 16,000-ray batches, images back on the host",
+                          "ms_per_pose": dt * 1e3, "ray_samples_per_s": s / dt}))
     if "c4" in which:      # config 4: 800x800, 64 coarse + 128 fine (192 in the fine pass), one GPU
         from nerf_simple_amd.utils.rendering import render_hierarchical_view
         for prec in ("fp16", "bf16"):
