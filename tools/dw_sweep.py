@@ -1,6 +1,6 @@
 """Time nerf_amd_param_gradients alone (HIP events) for a given point count.
 
-usage: python tools/dw_sweep.py [P]
+usage: python tools/dw_sweep.py [P] [path/to/libnerf_amd.so]     (a second build to compare against, as tools/ab_bench.py)
 (profiles/r01e_dw_sweep.jsonl holds the sweep of the per-slab cost term that chose the
 workgroup split now fixed in dw_gemm.hip; it was run with a temporary environment knob.)
 """
@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nerf_simple_amd import _lib
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 4096 * 64
+if len(sys.argv) > 2:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 lib = _lib.lib()
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
@@ -39,5 +41,5 @@ for _ in range(20):
     ts.append(a.elapsed_time(b))
 ts.sort()
 bytes_per_point = 11456
-print(json.dumps({"P": P, "ms_min": round(ts[0], 4),
+print(json.dumps({"lib": os.path.relpath(_lib.LIB_PATH), "P": P, "ms_min": round(ts[0], 4),
                   "ms_med": round(ts[len(ts) // 2], 4), "TBps_med": round(P * bytes_per_point / ts[len(ts) // 2] / 1e9, 3)}))
