@@ -253,8 +253,9 @@ int nerf_amd_sample_encode(const float* rays, const float* u, const float* tbins
                            float* posx, float* posd, float* ts, int64_t B, int N, void* stream);
 
 /* ---- fused training path of the dense layers (reference train.py:51-54) --------
- * bf16 ONLY: there is no fp32 / fp16 training kernel and no library fallback; a caller asking
- * for another training precision gets NERF_AMD_EUNSUP from its host wrapper.
+ * bf16 ONLY: the fused training kernels exist in bf16; a caller asking them for another precision gets
+ * NERF_AMD_EUNSUP from its host wrapper.  (Exact fp32 training is the layer-by-layer composition of
+ * nerf_amd_positional_encoder, nerf_amd_linear_f32 and the compositor's backward: at the end of this header.)
  * Forward as nerf_amd_mlp_forward_rays (bf16) that ALSO saves every layer's output for the
  * weight gradients (bf16; L0..L7 post-ReLU 256 features, L8 = the linear 256->256, L9 = colour
  * hidden 128; P = B*N points) in the point-blocked layout the kernels write and read with

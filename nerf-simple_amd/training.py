@@ -17,10 +17,12 @@ behind the C ABI, torch supplies tensors, streams, autograd bookkeeping and the 
                                                     torch.optim.Adam (reference train.py:43)
   the whole step as captured hipGraphs              GraphedTrainStep (below)
 
-Precision: the training kernels exist in bf16 only (gradients need bf16's exponent range; fp16
+Precision: the fused training kernels exist in bf16 only (gradients need bf16's exponent range; fp16
 would need loss scaling).  A module built with precision='bf16' or 'fp16' trains through them --
-``precision`` selects the INFERENCE kernel only -- and precision='fp32' raises: there is no fp32
-training path and no library-GEMM fallback (include/nerf_amd.h: NERF_AMD_EUNSUP).
+``precision`` selects the INFERENCE kernel only.  precision='fp32' trains EXACTLY, as the reference does
+(fp32 weights, activations and gradients: utils/generic_mlp.py, every nn.Linear and its backward on the
+strided fp32 MFMA GEMM nerf_amd_linear_f32, layer by layer): the slow, bit-faithful path -- its gradients match
+the reference's autograd to 1e-5 -- for checks and small problems; GraphedTrainStep is the fused bf16 step only.
 """
 
 import torch
@@ -152,10 +154,11 @@ def ctypes_stream(stream):
     return ctypes.c_void_p(stream.cuda_stream)
 
 
-def _check_trainable(precision):
+def _check_fused_trainable(precision):
     if _lib.precision_code(precision) == _lib.F32:
-        raise RuntimeError("fp32 training is not supported (NERF_AMD_EUNSUP): the training kernels are bf16; "
-                           "build the module with precision='bf16' (or 'fp16': bf16 training, fp16 inference)")
+        raise RuntimeError("the fused training step is bf16 (NERF_AMD_EUNSUP for precision='fp32'): build the module with "
+                           "precision='bf16' (or 'fp16': bf16 training, fp16 inference), or train the fp32 module with "
+                           "training.train_step (exact, layer by layer)")
 
 
 class _FusedDense(torch.autograd.Function):
@@ -229,8 +232,10 @@ class _FusedDense(torch.autograd.Function):
 
 def nerf_forward_autograd(net, v, precision):
     """Nerf.forward (reference utils/nets.py:34-43) with gradients to the parameters: the fused
-    training forward on points, v [P,6] -> [P,4]."""
-    _check_trainable(precision)
+    training forward on points, v [P,6] -> [P,4] (precision 'fp32': the exact layer-by-layer path)."""
+    if _lib.precision_code(precision) == _lib.F32:
+        from .utils import generic_mlp
+        return generic_mlp.forward(net, v)
     params = [p for _, p in net.named_parameters()]
     raw, _ = _FusedDense.apply(net, None, None, None, 0, 0, 0, 1, v.detach().contiguous(), *params)
     return raw.reshape(-1, 4)
@@ -240,7 +245,17 @@ def render_nerf_autograd(rays, net, N, tn, tf, jit, flags, precision, seed, ray_
     """render_nerf (reference utils/rendering.py:13-45) with gradients to the
     parameters of ``net``; returns the same 5-tuple."""
     from .utils.rendering import _tbins
-    _check_trainable(precision)
+    if _lib.precision_code(precision) == _lib.F32:
+        # exact fp32: the reference's own composition (sampling -> net.forward -> volume_render), each stage a HIP kernel
+        from .utils import generic_mlp
+        from .utils.rendering import ALL_OUTPUTS, _render_generic
+
+        class _Exact:
+            @staticmethod
+            def forward(q):
+                return generic_mlp.forward(net, q)
+
+        return _render_generic(rays, _Exact, N, tn, tf, jit, flags, ALL_OUTPUTS, seed, ray_id0)
     dev = rays.device
     params = [p for _, p in net.named_parameters()]
     raw, ts = _FusedDense.apply(net, rays, jit, _tbins(tn, tf, N, dev), flags, seed, ray_id0, N, None, *params)
@@ -262,7 +277,7 @@ def train_step(net, optimizer, rays, gt, N, *, tn=2, tf=6, u=None, decay=1.0, gr
     -> optimizer.step -> lr *= decay.  Returns the (detached) loss.
     Only ``rgb`` feeds the loss, as in the reference (train.py:52).
     The dense layers train in bf16 whatever the module's inference precision ('bf16' or 'fp16');
-    precision 'fp32' raises (no fp32 training kernels, no library fallback)."""
+    precision 'fp32' trains exactly, layer by layer in fp32 (utils/generic_mlp.py): slow, and the reference's numbers."""
     from . import parallel
     from .utils.rendering import render_nerf
     optimizer.zero_grad(set_to_none=True)
@@ -397,7 +412,7 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep needs optim.FusedAdam (one flat parameter vector)")
         if optimizer.net is not net:
             raise RuntimeError("the optimizer belongs to another module")
-        _check_trainable(net.precision)
+        _check_fused_trainable(net.precision)
         self.net, self.opt, self.group = net, optimizer, group
         if buckets not in (1, 2):
             raise ValueError("buckets must be 1 (one all-reduce between the two graphs, the default) or 2 (overlapped)")

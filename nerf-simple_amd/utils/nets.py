@@ -127,7 +127,7 @@ class Nerf(nn.Module):
                cycles, 5 % faster clock, 8-bit mantissa) or 'fp32' (exact-f32 MFMA).  Keyword-only
                superset of the reference signature.  It selects the INFERENCE kernel;
                with gradients enabled 'bf16' and 'fp16' modules both run the bf16
-               training kernels (training.py) and 'fp32' raises (no fp32 training path).
+               training kernels (training.py); 'fp32' trains exactly, layer by layer (utils/generic_mlp.py).
     """
 
     def __init__(self, Lp=10, Ld=4, H=256, *, precision=None):

@@ -109,12 +109,12 @@ def test_no_cpu_fallback():
     assert torch.equal(torch.get_rng_state(), state), "a refused call must not consume the CPU generator"
     with pytest.raises(AssertionError):
         xyz.gamma([1.0, 2.0])
-    # training precision contract, checked without a GPU: fp32 has no training kernels
+    # training precision contract, checked without a GPU: the fused (graphed) step is bf16; fp32 trains layer by layer
     from nerf_simple_amd import training
-    with pytest.raises(RuntimeError, match="fp32 training is not supported"):
-        training._check_trainable("fp32")
-    training._check_trainable("fp16")
-    training._check_trainable("bf16")
+    with pytest.raises(RuntimeError, match="the fused training step is bf16"):
+        training._check_fused_trainable("fp32")
+    training._check_fused_trainable("fp16")
+    training._check_fused_trainable("bf16")
 
 
 def test_state_dict_contract(synthetic):
