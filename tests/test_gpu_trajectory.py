@@ -80,6 +80,11 @@ def fused_step(dev, synthetic, rays, gt, u, N, graphed):
 
 # the bf16 kernels' gradient error against the reference's own minibatch sampling deviation (module docstring)
 GRAD_NOISE_RATIO = 0.5                       # e_k <= s_k / 2: the step's noise deviation grows by at most sqrt(1.25) = 12 %
+# precision='fp32' (the exact layer-by-layer path) over G8's 60 iterations: fp32 round-off only, 3x the observed
+EXACT_LOSS_RTOL = 7e-5                       # observed 2.2e-5 at step 59 (mean 3.6e-6); the bf16 step: 2.7e-3
+EXACT_VAL_RTOL = 6e-5                        # observed 1.8e-5 after 60 iterations
+EXACT_PARAM_RTOL = 4e-3                      # observed 1.4e-3 of the distance travelled (Adam's first step is lr * sign(g):
+                                             # entries whose gradient is ~0 land elsewhere); the bf16 step: 1e-2 ... 4e-2
 LOSS_RTOL = 1e-3                             # loss of one step: fp32 compositor on bf16 MLP outputs (observed 1.4e-4 ... 2.3e-4)
 
 
@@ -165,7 +170,7 @@ def test_train_step_reference_config(dev, golden, synthetic, oracle, graphed):
         assert abs(float(a.norm() / b.norm()) - 1) <= 1e-2, k
 
 
-def run_trajectory(dev, golden, oracle, synthetic, mode, seed_index=0):
+def run_trajectory(dev, golden, oracle, synthetic, mode, seed_index=0, precision="bf16"):
     from nerf_simple_amd.utils.nets import Nerf
     from nerf_simple_amd.optim import FusedAdam
     from nerf_simple_amd.training import train_step, GraphedTrainStep
@@ -188,7 +193,7 @@ def run_trajectory(dev, golden, oracle, synthetic, mode, seed_index=0):
                 rgb = render_nerf(val_rays, net, N, u=u_val, precision="fp32")[0]
             return float(torch.mean((rgb - val_gt) ** 2))
 
-        net = Nerf(precision="bf16").to(dev)
+        net = Nerf(precision=precision).to(dev)
         net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
         opt = FusedAdam(net, lr=5e-4)                       # torch.optim.Adam(net.parameters(), lr=5e-4), train.py:43
         stepper = GraphedTrainStep(net, opt, B, N) if mode == "graphed" else None
@@ -211,6 +216,36 @@ def run_trajectory(dev, golden, oracle, synthetic, mode, seed_index=0):
     finally:
         torch.set_rng_state(saved)
     return g, seed, np.asarray(losses), np.asarray(vals), snaps, rng_next, opt
+
+
+def test_training_trajectory_exact_fp32(dev, golden, oracle, synthetic):
+    """G8 again with a precision='fp32' module: the reference's loop in the reference's arithmetic (fp32 weights,
+    activations and gradients; layer-by-layer path).  What is left between the two runs is fp32 round-off (summation
+    order), so the bands are not the reference's seed spread but round-off growing over 60 Adam steps: the loss curve
+    within EXACT_LOSS_RTOL at every step, validation MSE within EXACT_VAL_RTOL, parameters within EXACT_PARAM_RTOL of
+    the distance travelled.  This pins the host side of the loop -- ray selection, jitter stream, Adam, decay -- with
+    no bf16 noise to hide behind."""
+    g, seed, losses, vals, snaps, rng_next, opt = run_trajectory(dev, golden, oracle, synthetic, "eager", precision="fp32")
+    seeds = [int(s) for s in g["seeds"]]
+    ref = g[f"loss/{seed}"]
+    rl = np.abs(losses - ref) / ref
+    refv = g[f"val/{seed}"].astype(np.float64)
+    dv = np.abs(vals - refv) / refv
+    sd0 = synthetic.synthetic_state_dict(0, "default")
+    perr = {}
+    for step, params in snaps.items():
+        num = den = 0.0
+        for k, p in params.items():
+            want, got = fixture_slice(g, f"step{step}", k, p.numpy())
+            _, p0 = fixture_slice(g, f"step{step}", k, sd0[k].numpy())
+            num += float(np.sum((got.astype(np.float64) - want) ** 2))
+            den += float(np.sum((want.astype(np.float64) - p0) ** 2))
+        perr[step] = float(np.sqrt(num / den))
+    print(f"G8 fp32: loss deviation max {rl.max():.3e} (step {int(rl.argmax())}), mean {rl.mean():.3e}; validation {dv}; parameters {perr}")
+    assert np.array_equal(rng_next, g["rng_next"])
+    assert rl.max() <= EXACT_LOSS_RTOL, rl.max()
+    assert dv.max() <= EXACT_VAL_RTOL, dv
+    assert max(perr.values()) <= EXACT_PARAM_RTOL, perr
 
 
 @pytest.mark.parametrize("mode", ["eager", "graphed"])
