@@ -11,8 +11,8 @@
 //                                           or a single 1.0f with both strides 0 (column sums = bias gradients)
 //
 // Exact fp32 products and fp32 accumulation (the MFMA is an fma chain); a correct, tidy kernel rather than a tuned
-// one: 64 x 64 output tile per workgroup of four waves, K in steps of 16 through LDS, loads coalesced along whichever
-// index is contiguous.  Long reductions with few output tiles (dW: K = number of points) are split over blockIdx.z and
+// one: 64 x 64 output tile per workgroup of four waves, K in steps of 16 through LDS (the next step's operands are
+// fetched into registers under the current step's MFMAs), loads coalesced along whichever index is contiguous.  Long reductions with few output tiles (dW: K = number of points) are split over blockIdx.z and
 // summed with float atomics.
 #include "nerf_device.h"
 
@@ -51,28 +51,45 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs a) {
         for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool a_i_fast = a.sa_i == 1 && a.sa_k != 1;            // consecutive threads along the contiguous index
     const bool b_j_fast = a.sb_j == 1 || a.sb_k != 1;
-    for (long long k0 = k_lo; k0 < k_hi; k0 += TK) {
+    // this thread's four elements of each operand tile: (row / column, k) inside the tile
+    constexpr int RA = TM * TK / 256, RB = TN * TK / 256;
+    int ai[RA], ak[RA], bj[RB], bk[RB];
 #pragma unroll
-        for (int r = 0; r < TM * TK / 256; ++r) {
-            const int e = tid + 256 * r;
-            const int i = a_i_fast ? e % TM : e / TK, k = a_i_fast ? e / TM : e % TK;
+    for (int r = 0; r < RA; ++r) {
+        const int e = tid + 256 * r;
+        ai[r] = a_i_fast ? e % TM : e / TK;
+        ak[r] = a_i_fast ? e / TM : e % TK;
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        const int e = tid + 256 * r;
+        bj[r] = b_j_fast ? e % TN : e / TK;
+        bk[r] = b_j_fast ? e / TN : e % TK;
+    }
+    float ra[RA], rb[RB];
+    auto fetch = [&](long long k0) {              // global -> registers (zeros outside the matrices / this K range)
+#pragma unroll
+        for (int r = 0; r < RA; ++r) {
             float v = 0.f;
-            if (i0 + i < a.M && k0 + k < k_hi) {
-                const long long off = (i0 + i) * a.sa_i + (k0 + k) * a.sa_k;
+            if (i0 + ai[r] < a.M && k0 + ak[r] < k_hi) {
+                const long long off = (i0 + ai[r]) * a.sa_i + (k0 + ak[r]) * a.sa_k;
                 v = a.A[off];
                 if (a.A_mask && !(a.A_mask[off] > 0.f)) v = 0.f;
             }
-            As[k][i] = v;
+            ra[r] = v;
         }
 #pragma unroll
-        for (int r = 0; r < TN * TK / 256; ++r) {
-            const int e = tid + 256 * r;
-            const int j = b_j_fast ? e % TN : e / TK, k = b_j_fast ? e / TN : e % TK;
-            float v = 0.f;
-            if (j0 + j < a.N && k0 + k < k_hi) v = a.B[(k0 + k) * a.sb_k + (j0 + j) * a.sb_j];
-            Bs[k][j] = v;
-        }
+        for (int r = 0; r < RB; ++r)
+            rb[r] = (j0 + bj[r] < a.N && k0 + bk[r] < k_hi) ? a.B[(k0 + bk[r]) * a.sb_k + (j0 + bj[r]) * a.sb_j] : 0.f;
+    };
+    if (k_lo < k_hi) fetch(k_lo);
+    for (long long k0 = k_lo; k0 < k_hi; k0 += TK) {
+#pragma unroll
+        for (int r = 0; r < RA; ++r) As[ak[r]][ai[r]] = ra[r];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) Bs[bk[r]][bj[r]] = rb[r];
         __syncthreads();
+        if (k0 + TK < k_hi) fetch(k0 + TK);        // the next step's loads fly under this step's MFMAs
 #pragma unroll
         for (int ks = 0; ks < TK / 4; ++ks) {
             const int kk = 4 * ks + (lane >> 4);

@@ -56,22 +56,28 @@ class _GenericMlp(torch.autograd.Function):
         P, H = v.shape[0], w[0].shape[0]
         new = lambda n: torch.empty((P, n), dtype=torch.float32, device=v.device)    # noqa: E731
         posx, posd = positional_encoder(v.detach(), Lp, Ld)
-        acts = []                                  # post-ReLU outputs of layers 0..7, f, c1 (what the backward needs)
+        keep = any(ctx.needs_input_grad[3:])
+        acts = []                                  # post-ReLU outputs of layers 0..7 (what the backward needs)
         h = posx
         for L in range(5):
             y = new(H)
             _linear(h, w[L], b[L], y, relu=True)
-            acts.append(y)
+            if keep:
+                acts.append(y)
             h = y
         y = new(H)                                 # skip: cat(h, posx) @ W^T = h @ W[:, :H]^T + posx @ W[:, H:]^T
         _linear(h, w[5], b[5], y, relu=False)
         _linear(posx, w[5], None, y, relu=True, w_col0=H, accumulate=True)
-        acts.append(y)
+        if keep:
+            acts.append(y)
+        else:
+            del posx
         h = y
         for L in (6, 7):
             y = new(H)
             _linear(h, w[L], b[L], y, relu=True)
-            acts.append(y)
+            if keep:
+                acts.append(y)
             h = y
         out = new(4)
         _linear(h, w[8], b[8], out, relu=False, out_col0=3)                          # sigma -> out[:, 3]
@@ -81,7 +87,7 @@ class _GenericMlp(torch.autograd.Function):
         _linear(f, w[10], b[10], c1, relu=False)
         _linear(posd, w[10], None, c1, relu=True, w_col0=H, accumulate=True)
         _linear(c1, w[11], b[11], out, relu=False)                                   # rgb -> out[:, 0:3]
-        if any(ctx.needs_input_grad[3:]):
+        if keep:
             ctx.save_for_backward(posx, posd, f, c1, *acts, *w)
         ctx.shapes = (P, H)
         return out
@@ -154,6 +160,9 @@ class _GenericMlp(torch.autograd.Function):
         return (None, None, None, *grads)
 
 
+INFERENCE_CHUNK = 1 << 20      # points per pass without gradients: bounds the activations in HBM (~ 6 x H x 4 B per point live)
+
+
 def forward(net, v):
     """Nerf.forward(v) for a module of any (Lp, Ld, H): [P, 6] -> [P, 4] fp32, with gradients for the parameters."""
     params = []
@@ -161,4 +170,11 @@ def forward(net, v):
     for name in LAYER_NAMES:
         m = mods[name]
         params += [m.weight, m.bias]
-    return _GenericMlp.apply(v, net.Lp, net.Ld, *params)
+    needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+    if needs_grad or v.shape[0] <= INFERENCE_CHUNK:
+        return _GenericMlp.apply(v, net.Lp, net.Ld, *params)
+    # inference on many points (an image's worth of samples): chunk by chunk, nothing kept between chunks
+    out = torch.empty((v.shape[0], 4), dtype=torch.float32, device=v.device)
+    for s in range(0, v.shape[0], INFERENCE_CHUNK):
+        out[s:s + INFERENCE_CHUNK] = _GenericMlp.apply(v[s:s + INFERENCE_CHUNK], net.Lp, net.Ld, *params)
+    return out
