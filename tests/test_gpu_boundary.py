@@ -372,6 +372,39 @@ def test_non_finite_inputs_propagate_like_the_reference(dev, oracle, synthetic, 
         assert np.abs(a[ok] - b[ok]).max() <= 1e-4 * max(1.0, np.abs(b[ok]).max()), (precision, name)   # it IS the fp32 kernel by now
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16", "fp32"])
+def test_non_finite_weights_propagate_like_the_reference(dev, oracle, synthetic, precision):
+    """A checkpoint with a NaN in it (a diverged run saved to disk): one weight of layers_0.2, and -- separately -- an
+    infinite bias of layers_1.0.  In the reference the NaN spreads to every output of every ray (NaN * h in one row, then
+    every row of the next layer).  A 16-bit kernel's integer ReLU could wash that row to zero and render a plausible
+    picture from a broken network; the packer flags non-finite weights, so these weights render with the fp32 kernel
+    (with a warning) and come out as the reference's do."""
+    import warnings as _w
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import render_nerf
+    rays = scene_rays(oracle, synthetic, 6)
+    N = 16
+    u = torch.rand(rays.shape[0], N, generator=torch.Generator().manual_seed(3))
+    for key, index, value in (("layers_0.2.weight", (209, 112), float("nan")), ("layers_1.0.bias", (7,), float("inf"))):
+        sd = {k: v.clone() for k, v in synthetic.synthetic_state_dict(0, "structured").items()}
+        sd[key][index] = value
+        with torch.no_grad():
+            want = oracle.render_nerf(rays, sd, N, u=u)
+        net = Nerf(precision=precision).to(dev)
+        net.load_state_dict(sd)
+        with torch.no_grad(), _w.catch_warnings(record=True) as caught:
+            _w.simplefilter("always")
+            got = render_nerf(rays.to(dev), net, N, u=u.to(dev))
+        if precision != "fp32":
+            assert any("not finite" in str(w.message) or "non-finite" in str(w.message) for w in caught), [str(w.message) for w in caught]
+        for name, a, b in zip(("rgb", "disp", "alpha", "acc", "w"), got, want):
+            a, b = a.cpu().numpy(), b.numpy()
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (precision, key, name, int(np.isnan(a).sum()), int(np.isnan(b).sum()))
+            ok = np.isfinite(b)
+            if ok.any():
+                assert np.abs(a[ok] - b[ok]).max() <= 1e-4 * max(1.0, np.abs(b[ok]).max()), (precision, key, name)
+
+
 def test_render_beyond_two_to_the_31_samples(dev, synthetic):
     """A batch whose sample count does not fit 32 bits: 17,000,000 rays x 128 samples = 2.176e9 ray-samples in ONE call
     (the C ABI's sizes are int64).  Every index on the path -- point ids, the counter RNG's sample counter, per-workgroup
