@@ -173,6 +173,17 @@ class _FusedDense(torch.autograd.Function):
         src = rays if rays is not None else pts
         B, dev = src.size(0), src.device
         P = B * N
+        # a diverged run is loud: the status words of the previous forwards (non-finite activations / weights) are
+        # looked at here, without waiting (_StatusWatch below; the graphed step does the same)
+        watch = net.__dict__.get("_watch")
+        if watch is None:
+            watch = net.__dict__["_watch"] = _StatusWatch()
+            net.__dict__["_watch_calls"] = 0
+        bad = watch.poll()
+        if bad is not None:
+            what = " and ".join(w for w, on in (("activations", bad[1]), ("weights", bad[2])) if on)
+            raise FloatingPointError(f"non-finite values inside the network in training forward {bad[0]} ({what}): "
+                                     "NaN / inf weights or inputs, the run has diverged")
         packed = net.packed_weights(_lib.BF16)
         raw = torch.empty((B, N, 4), dtype=torch.float32, device=dev)
         ts = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -196,6 +207,8 @@ class _FusedDense(torch.autograd.Function):
                     "nerf_amd_mlp_forward_train_points")
                 _lib.check(lib.nerf_amd_encode_points_bf16(_lib.ptr(pts), _lib.ptr(posx), _lib.ptr(posd), P, st),
                            "nerf_amd_encode_points_bf16")
+        net.__dict__["_watch_calls"] += 1
+        watch.push(packed, net.__dict__["_watch_calls"])
         ctx.net, ctx.P = net, P
         ctx.shapes = [tuple(p.shape) for p in params]
         ctx.save_for_backward(acts, posx, posd)

@@ -163,6 +163,8 @@ class Nerf(nn.Module):
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_packed"] = {}
+        state.pop("_watch", None)                # training.py's status watch: pinned words and events
+        state.pop("_watch_calls", None)
         return state
 
     def __setstate__(self, state):

@@ -712,3 +712,28 @@ def test_diverged_training_is_loud(dev, golden, synthetic):
         for _ in range(4):
             stepper.step(rays, gt, u=u)
             torch.cuda.synchronize()
+
+
+def test_diverged_eager_training_is_loud(dev, golden, synthetic):
+    """The eager step (train_step, Nerf.forward with gradients) watches the same status words as the graphed one: a NaN
+    weight that the integer ReLU would turn into a dead unit -- finite loss, broken network -- raises at a later call;
+    a healthy run never does, and copies of the module do not carry the watch."""
+    import copy
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.training import train_step
+    g = golden("train.npz")
+    rays, gt, u, N = t(g["rays"]).to(dev), t(g["gt"]).to(dev), t(g["u"]).to(dev), int(g["N"])
+    net = Nerf(precision="bf16").to(dev)
+    net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    for _ in range(4):
+        loss = train_step(net, opt, rays, gt, N, u=u)
+        torch.cuda.synchronize()
+    assert np.isfinite(float(loss))
+    assert "_watch" in net.__dict__ and "_watch" not in copy.deepcopy(net).__dict__
+    with torch.no_grad():
+        net.layers_0[2].weight[209, 112] = float("nan")
+    with pytest.raises(FloatingPointError, match="non-finite values inside the network"):
+        for _ in range(3):
+            train_step(net, opt, rays, gt, N, u=u)
+            torch.cuda.synchronize()
