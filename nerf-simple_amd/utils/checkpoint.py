@@ -23,14 +23,15 @@ def load_checkpoint(net, path, map_location="cpu"):
     """Load a reference (or own) ``.pth`` into ``net`` with ``strict=True``.
     The file is read with ``weights_only=True``: nothing in it is executed."""
     sd = torch.load(path, map_location=map_location, weights_only=True)
-    check_state_dict(sd)
+    check_state_dict(sd, net)
     net.load_state_dict(sd, strict=True)
     return net
 
 
-def check_state_dict(sd):
-    """Raise unless ``sd`` has exactly the reference's 24 keys and shapes."""
-    want = dict(PARAM_SPECS)
+def check_state_dict(sd, net=None):
+    """Raise unless ``sd`` has exactly the reference's 24 keys with the shapes of ``net`` (a Nerf of any
+    (Lp, Ld, H)); without ``net``: the shapes of the default Nerf()."""
+    want = dict(PARAM_SPECS) if net is None else {k: tuple(v.shape) for k, v in net.state_dict().items()}
     if set(sd.keys()) != set(want):
         missing, extra = set(want) - set(sd), set(sd) - set(want)
         raise KeyError(f"not a Nerf checkpoint: missing {sorted(missing)}, unexpected {sorted(extra)}")

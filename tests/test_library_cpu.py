@@ -247,6 +247,15 @@ def test_checkpoint_roundtrip(tmp_path, synthetic):
     torch.save(bad, str(tmp_path / "bad.pth"))
     with pytest.raises(KeyError):
         checkpoint.load_checkpoint(Nerf(), str(tmp_path / "bad.pth"))
+    # a module of another size: its own checkpoint loads, the default one is refused with the offending tensor named
+    small = Nerf(6, 2, 128)
+    p2 = checkpoint.save_checkpoint(small, str(tmp_path / "small.pth"))
+    again = checkpoint.load_checkpoint(Nerf(6, 2, 128), p2)
+    assert all(torch.equal(x, y) for x, y in zip(small.state_dict().values(), again.state_dict().values()))
+    with pytest.raises(ValueError, match="layers_0.0.weight"):
+        checkpoint.load_checkpoint(Nerf(6, 2, 128), path)
+    with pytest.raises(ValueError, match="layers_0.0.weight"):
+        checkpoint.load_checkpoint(Nerf(), p2)
 
 
 def test_counted_vmcnt_waits():
