@@ -103,8 +103,15 @@ class _GenericMlp(torch.autograd.Function):
         dev = g_out.device
         g = _lib.require_cuda_f32(g_out, "grad").contiguous()
         one = torch.ones(1, dtype=torch.float32, device=dev)
-        gw = [torch.zeros_like(x) for x in w]
-        gb = [torch.zeros(x.shape[0], dtype=torch.float32, device=dev) for x in w]
+        # all 24 gradients as consecutive views of ONE flat vector in state_dict order, like the fused backward's: the
+        # data-parallel exchange is one all-reduce of it and FusedAdam reads it in place (parallel.flat_grad_view)
+        flat = torch.zeros(sum(x.numel() + x.shape[0] for x in w), dtype=torch.float32, device=dev)
+        gw, gb, off = [], [], 0
+        for x in w:
+            gw.append(flat[off:off + x.numel()].view(x.shape))
+            off += x.numel()
+            gb.append(flat[off:off + x.shape[0]])
+            off += x.shape[0]
         new = lambda n: torch.empty((P, n), dtype=torch.float32, device=dev)         # noqa: E731
 
         def wgrad(L, dy, ld_dy, n_out, x, *, dy_off=0, mask=None, w_col0=0):

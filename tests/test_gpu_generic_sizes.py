@@ -134,6 +134,9 @@ def test_gradients_any_size_vs_oracle_autograd(dev, oracle, Lp, Ld, H):
         assert p.grad is not None and p.grad.shape == ref[k].grad.shape, k
         worst[k] = rel_err(p.grad, ref[k].grad)
     assert max(worst.values()) <= REL, worst
+    from nerf_simple_amd.parallel import flat_grad_view
+    flat = flat_grad_view([p for _, p in net.named_parameters()])       # one bucket for the all-reduce / FusedAdam
+    assert flat is not None and flat.numel() == sum(p.numel() for p in net.parameters())
 
 
 def test_render_and_training_step_any_size(dev, oracle):
