@@ -70,10 +70,26 @@ def main():
     assert span >= exposed >= 0.0
     res["params4"] = opt.flat.cpu().numpy()
     res["collective_ms"] = np.array([span, exposed])
+    # the eager step under the group, on the exact layer-by-layer path: a precision='fp32' module and one of another size
+    from nerf_simple_amd.training import train_step
+    from nerf_simple_amd.parallel import flat_grad_view
+    for tag, make in (("exact", lambda: Nerf(precision="fp32")), ("small", lambda: Nerf(6, 2, 128))):
+        torch.manual_seed(5)                                           # same initial weights on both ranks
+        m = make().to(dev)
+        if tag == "exact":
+            m.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+        parallel.broadcast_parameters(m)
+        o = FusedAdam(m, lr=5e-4)
+        l = train_step(m, o, rays[sl].to(dev), gt[sl].to(dev), N, u=uu[sl].to(dev), group=dist.group.WORLD)
+        res[f"{tag}_grads"] = flat_grad_view([p for _, p in m.named_parameters()]).cpu().numpy()
+        res[f"{tag}_params"] = o.flat.cpu().numpy()
+        res[f"{tag}_loss"] = np.array([float(l)])
     if rank == 0:
         np.savez(os.path.join(out_dir, "rank0.npz"), **res)
     else:
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=res["loss"], params=res["params"], params4=res["params4"])
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), loss=res["loss"], params=res["params"], params4=res["params4"],
+                 exact_params=res["exact_params"], small_params=res["small_params"],
+                 exact_loss=res["exact_loss"], small_loss=res["small_loss"])
     dist.barrier()
     dist.destroy_process_group()
 
