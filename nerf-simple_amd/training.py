@@ -579,16 +579,26 @@ class GraphedTrainStep:
                                      "NaN / inf weights or inputs, the run has diverged")
         self.rays.copy_(rays, non_blocking=True)
         self.gt.copy_(gt, non_blocking=True)
+        pending = None
         if self.device_rng:
             if u is not None:
                 raise RuntimeError("this GraphedTrainStep draws its jitter on the device (device_rng=True): u must be None")
         else:
             if u is None:
-                # the reference's one draw per call from torch's CPU generator, continued on the device
+                # the reference's one draw per call from torch's CPU generator, continued on the device; the generator is
+                # made current again (pending.finish: a wait for the generator kernel alone) once the whole step is
+                # enqueued behind it, so the host never waits for the previous step here
                 from .utils.host_rng import reference_rand
                 u, pending = reference_rand(self.B, self.N, self.dev)
-                pending.finish()
             self.u.copy_(u, non_blocking=True)
+        try:
+            return self._enqueue_step(decay)
+        finally:
+            if pending is not None:
+                pending.finish()
+
+    def _enqueue_step(self, decay):
+        from . import parallel
         self.opt.step_count += 1
         self._set_hyper(self.opt.step_count)
         self.graph_a.replay()
