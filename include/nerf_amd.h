@@ -341,7 +341,9 @@ int nerf_amd_mt19937_uniform(const uint32_t* state624, int next, float* out, int
  * advanced by b * seg_words words, obtained by MT19937 jump-ahead -- polys[m][624] holds
  * x^(seg_words * 2^m) mod the characteristic polynomial (utils/mt19937_jump.npz, made and verified by
  * tools/make_mt_jump.py), m < levels, and the start states follow from the first by a doubling
- * tree of GF(2) convolutions.  seg_states: workspace of nerf_amd_mt19937_segments(next, n,
+ * tree of GF(2) convolutions.  levels < 0 selects the one-launch form for short draws instead:
+ * polys[j-1][624] holds x^(seg_words * j), j = 1 .. -levels, and every start state is formed from the
+ * first directly (up to 1 - levels segments).  seg_states: workspace of nerf_amd_mt19937_segments(next, n,
  * seg_words) * 624 words.  Values and final state identical to nerf_amd_mt19937_uniform. */
 int64_t nerf_amd_mt19937_segments(int next, int64_t n, int64_t seg_words);
 int nerf_amd_mt19937_uniform_par(const uint32_t* state624, int next, float* out, int64_t n,

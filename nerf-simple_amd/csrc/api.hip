@@ -531,12 +531,12 @@ int64_t nerf_amd_mt19937_segments(int next, int64_t n, int64_t seg_words) {
 int nerf_amd_mt19937_uniform_par(const uint32_t* state624, int next, float* out, int64_t n, uint32_t* state_out624,
                                  const uint32_t* polys, int levels, int64_t seg_words, uint32_t* seg_states,
                                  void* stream) {
-    if (n < 0 || next < 0 || next > 624 || levels < 0 || levels > 30) return NERF_AMD_EINVAL;
+    if (n < 0 || next < 0 || next > 624 || levels < -4096 || levels > 30) return NERF_AMD_EINVAL;
     if (seg_words <= 0 || seg_words % 624) return NERF_AMD_EINVAL;
     if (!state624 || !state_out624 || (n > 0 && !out)) return NERF_AMD_EINVAL;
     const int64_t nseg = nerf_amd_mt19937_segments(next, n, seg_words);
     if (nseg > 1 && (!polys || !seg_states)) return NERF_AMD_EINVAL;
-    if (nseg > ((int64_t)1 << levels)) return NERF_AMD_EUNSUP;
+    if (levels >= 0 ? nseg > ((int64_t)1 << levels) : nseg > 1 - (int64_t)levels) return NERF_AMD_EUNSUP;
     return nerf_amd_launch_mt19937_uniform_par(state624, next, out, n, state_out624, polys, levels, seg_words, seg_states,
                                                S(stream));
 }

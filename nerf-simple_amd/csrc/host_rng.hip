@@ -141,17 +141,21 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __
 constexpr int MT_JUMP_BLOCKS = 33;                       // 33 * 624 = 20592 >= 19937 + 623 words
 constexpr int MT_DEG = 19937;
 
-constexpr int MT_JUMP_SPLIT = 8;                         // workgroups sharing one jump's convolution (624 = 8 * 78 words)
+constexpr int MT_JUMP_SPLIT = 16;                        // workgroups sharing one jump's convolution (624 = 16 * 39 words)
 
-__global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict__ states, const unsigned* __restrict__ poly,
-                                                           int src0, int dst0) {
+// Jump j of a launch reads state src0 + j * src_step with polynomial polys[j * poly_step]: the doubling tree uses
+// (src_step, poly_step) = (1, 0) -- 2^m states advanced by the same distance -- and the one-launch form (0, 1): every
+// start state straight from state 0, each with its own polynomial.
+__global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict__ states, const unsigned* __restrict__ polys,
+                                                           int src0, int dst0, int src_step, int poly_step) {
     // blockIdx.x = jump * MT_JUMP_SPLIT + part: the parts of a jump each rebuild the word sequence (cheap)
     // and convolve a slice of the polynomial, combining into the zero-initialised destination with atomicXor
     const int jump = blockIdx.x / MT_JUMP_SPLIT, part = blockIdx.x % MT_JUMP_SPLIT;
     extern __shared__ unsigned w[];                       // [MT_JUMP_BLOCKS * 624] + the polynomial [624]
     unsigned* gp = w + MT_JUMP_BLOCKS * MT_N;             // (624 dependent global loads cost 0.6 ms)
     const int t = threadIdx.x;
-    const unsigned* src = states + (long long)(src0 + jump) * MT_N;
+    const unsigned* src = states + (long long)(src0 + jump * src_step) * MT_N;
+    const unsigned* poly = polys + (long long)jump * poly_step * MT_N;
     for (int i = t; i < MT_N; i += 256) {
         w[i] = src[i];
         gp[i] = poly[i];
@@ -203,6 +207,8 @@ __global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict_
 
 // Parallel form: the stream is cut into segments of seg_words words (a multiple of 624) after the
 // generator's unread words; polys[m] = x^(seg_words * 2^m) mod phi; seg_states: workspace [S][624].
+// levels > 0: polys[m] = x^(seg_words * 2^m) mod phi, doubling tree (up to 2^levels segments);
+// levels < 0: polys[j-1] = x^(seg_words * j) mod phi, j = 1 .. -levels, every start state in ONE launch.
 extern "C" int nerf_amd_launch_mt19937_uniform_par(const uint32_t* state_in, int next, float* out, long long n,
                                                    uint32_t* state_out, const uint32_t* polys, int levels,
                                                    long long seg_words, uint32_t* seg_states, hipStream_t stream) {
@@ -210,7 +216,7 @@ extern "C" int nerf_amd_launch_mt19937_uniform_par(const uint32_t* state_in, int
     const long long avail = MT_N - next;
     long long S = 1;
     if (n > avail + seg_words) S = 1 + (n - avail - seg_words + seg_words - 1) / seg_words;
-    if (S > (1ll << levels)) return -2;
+    if (levels >= 0 ? S > (1ll << levels) : S > 1 - (long long)levels) return -2;
     if (S > 1) {
         hipError_t e = hipMemsetAsync(seg_states, 0, (size_t)S * MT_N * sizeof(uint32_t), stream);   // atomicXor targets
         if (e != hipSuccess) return (int)e;
@@ -220,11 +226,16 @@ extern "C" int nerf_amd_launch_mt19937_uniform_par(const uint32_t* state_in, int
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt19937_jump_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return (int)e;
-        for (int m = 0; (1ll << m) < S; ++m) {                      // doubling tree over the segment start states
-            const long long have = 1ll << m;
-            const long long count = S - have < have ? S - have : have;
-            hipLaunchKernelGGL(mt19937_jump_kernel, dim3((unsigned)(count * MT_JUMP_SPLIT)), dim3(256), lds, stream, seg_states,
-                               polys + (long long)m * MT_N, 0, (int)have);
+        if (levels < 0) {                                           // every start state from state 0, one launch
+            hipLaunchKernelGGL(mt19937_jump_kernel, dim3((unsigned)((S - 1) * MT_JUMP_SPLIT)), dim3(256), lds, stream, seg_states,
+                               polys, 0, 1, 0, 1);
+        } else {
+            for (int m = 0; (1ll << m) < S; ++m) {                  // doubling tree over the segment start states
+                const long long have = 1ll << m;
+                const long long count = S - have < have ? S - have : have;
+                hipLaunchKernelGGL(mt19937_jump_kernel, dim3((unsigned)(count * MT_JUMP_SPLIT)), dim3(256), lds, stream,
+                                   seg_states, polys + (long long)m * MT_N, 0, (int)have, 1, 0);
+            }
         }
     }
     hipLaunchKernelGGL(mt19937_uniform_kernel, dim3((unsigned)S), dim3(512), 0, stream, state_in, next, out, n, state_out,

@@ -87,14 +87,16 @@ _jump = {}
 
 
 def _jump_polys(device):
-    """(polys [levels, 624] on ``device``, levels, seg_words) from utils/mt19937_jump.npz, or None."""
+    """(polys [levels, 624] on ``device``, levels, seg_words, short_polys [15, 624], short_seg_words) from
+    utils/mt19937_jump.npz, or None."""
     key = str(device)
     if key not in _jump:
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mt19937_jump.npz")
         try:
             z = np.load(path)
             polys = torch.from_numpy(z["polys"].astype(np.uint32).view(np.int32)).to(device)
-            _jump[key] = (polys, int(polys.shape[0]), int(z["seg_words"]))
+            short = torch.from_numpy(z["short_polys"].astype(np.uint32).view(np.int32)).to(device)
+            _jump[key] = (polys, int(polys.shape[0]), int(z["seg_words"]), short, int(z["short_seg_words"]))
         except Exception:
             _jump[key] = None
     return _jump[key]
@@ -106,9 +108,15 @@ def _launch_uniform(words_dev, next0, out, n, state_out, device):
     st = _lib.stream_ptr(device)
     jp = _jump_polys(device)
     if jp is not None:
-        polys, levels, seg_words = jp
+        polys, levels, seg_words, short, short_words = jp
         S = int(lib.nerf_amd_mt19937_segments(int(next0), int(n), seg_words))
-        if 1 < S <= (1 << levels):
+        if S == 1:
+            # shorter than one long segment (a training batch): the finer cut, all start states in one launch
+            S = int(lib.nerf_amd_mt19937_segments(int(next0), int(n), short_words))
+            polys, levels, seg_words = short, -int(short.shape[0]), short_words
+            if S > 1 - levels:
+                S = 1
+        if 1 < S <= ((1 << levels) if levels > 0 else 1 - levels):
             ws = torch.empty((S, _N), dtype=torch.int32, device=device)
             _lib.check(lib.nerf_amd_mt19937_uniform_par(_lib.ptr(words_dev), int(next0), _lib.ptr(out), int(n),
                                                         _lib.ptr(state_out), _lib.ptr(polys), levels, seg_words,

@@ -747,7 +747,9 @@ def test_reference_rand_is_torch_rand(dev, oracle):
     saved = torch.get_rng_state()
     try:
         for seed, pre, shape in ((0, 0, (3, 5)), (1, 3, (7, 100)), (2, 623, (1, 5)), (3, 624, (13, 100)), (4, 100, (1, 624)),
-                                 (5, 0, (1000, 128)), (6, 77, (4096, 64)), (7, 500, (300, 2080)),
+                                 # training-batch sizes: the finer cut, every start state in one jump launch (4 .. 16 segments)
+                                 (5, 0, (1000, 128)), (6, 77, (4096, 64)), (7, 500, (300, 2080)), (12, 0, (4096, 128)),
+                                 (13, 17, (4992, 128)), (14, 624, (5000, 128)), (15, 1, (39936 + 623, 1)), (16, 1, (39936 + 624, 1)),
                                  # several segments: jump-ahead start states + one workgroup per segment
                                  (8, 0, (40000, 128)), (9, 333, (100000, 128)), (10, 624, (19968, 128)),
                                  (11, 100, (19969, 128))):

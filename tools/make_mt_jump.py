@@ -11,7 +11,8 @@ F^i applied to the state is the window w_i .. w_{i+623}, hence
 -- a GF(2) convolution over 19937 + 624 words that csrc/host_rng.hip evaluates in parallel.
 phi is found with Berlekamp-Massey on one output bit (Python integers as bit vectors), g_J by
 square-and-multiply.  Polynomials for J = SEG_WORDS * 2^m, m = 0 .. M-1, are stored so that the
-start states of up to 2^M segments follow from the first by a doubling tree.
+start states of up to 2^M segments follow from the first by a doubling tree; for draws shorter than one
+such segment a finer cut is stored with the polynomial of every multiple (J = SHORT_SEG_WORDS * j, j = 1 .. 15).
 
 Everything here is checked again by tests/test_oracle_golden.py (phi recomputed, a jump compared
 with plain sequential generation)."""
@@ -24,6 +25,11 @@ DEG = 19937
 SEG_BLOCKS = 1024                      # a segment = 1024 blocks of 624 words = 638,976 draws
 SEG_WORDS = SEG_BLOCKS * N
 LEVELS = 10                            # up to 1024 segments (6.5e8 draws) per call
+# draws of a training batch (4096 rays x 64 .. 128 samples = 2.6e5 .. 5.2e5) fit ONE such segment: a second, finer cut
+# with the polynomial of every multiple stored, so that all start states follow from the first in ONE launch
+SHORT_SEG_BLOCKS = 64                  # 39,936 draws
+SHORT_SEG_WORDS = SHORT_SEG_BLOCKS * N
+SHORT_COUNT = 15                       # x^(j * SHORT_SEG_WORDS), j = 1 .. 15: up to 16 segments = one long segment
 
 
 def raw_words(state, nblocks):
@@ -126,8 +132,9 @@ def apply_jump(state, gwords):
 if __name__ == "__main__":
     phi = char_poly()
     polys = np.stack([to_words(x_pow_mod(SEG_WORDS << m, phi)) for m in range(LEVELS)])
+    short_polys = np.stack([to_words(x_pow_mod(SHORT_SEG_WORDS * j, phi)) for j in range(1, SHORT_COUNT + 1)])
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nerf-simple_amd", "utils",
                        "mt19937_jump.npz")
     np.savez_compressed(dst, seg_words=np.int64(SEG_WORDS), polys=polys, phi=to_words(phi),
-                        phi_top=np.int64(phi >> (32 * N)))
-    print("wrote", dst, polys.shape, "phi weight", phi.bit_count())
+                        phi_top=np.int64(phi >> (32 * N)), short_seg_words=np.int64(SHORT_SEG_WORDS), short_polys=short_polys)
+    print("wrote", dst, polys.shape, short_polys.shape, "phi weight", phi.bit_count())
