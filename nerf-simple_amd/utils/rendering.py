@@ -115,14 +115,18 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
         # the reference's single CPU draw per call (:28-30): same numbers, same advance of torch's
         # CPU generator, produced on the device (host_rng.py)
         jit, pending_rng = reference_rand(B, N, dev)
-    if pending_rng is not None and (training or not fused):
-        pending_rng.finish()                  # user / autograd code follows: the generator must be current
+    if pending_rng is not None and not fused:
+        pending_rng.finish()                  # the net's own forward follows: the generator must be current
         pending_rng = None
     if training:
         from ..training import render_nerf_autograd
-        return render_nerf_autograd(rays, net, N, tn, tf, jit, flags,
-                                    net.precision if precision is None else precision,
-                                    seed, ray_id0)
+        try:
+            return render_nerf_autograd(rays, net, N, tn, tf, jit, flags,
+                                        net.precision if precision is None else precision,
+                                        seed, ray_id0)
+        finally:
+            if pending_rng is not None:
+                pending_rng.finish()          # the forward is enqueued behind the generator kernel: only that is awaited
     if not fused:
         return _render_generic(rays, net, N, tn, tf, jit, flags, outputs, seed, ray_id0)
 
