@@ -343,7 +343,7 @@ int nerf_amd_mt19937_uniform(const uint32_t* state624, int next, float* out, int
  * tools/make_mt_jump.py), m < levels, and the start states follow from the first by a doubling
  * tree of GF(2) convolutions.  levels < 0 selects the one-launch form for short draws instead:
  * polys[j-1][624] holds x^(seg_words * j), j = 1 .. -levels, and every start state is formed from the
- * first directly (up to 1 - levels segments).  seg_states: workspace of nerf_amd_mt19937_segments(next, n,
+ * first directly (up to 1 - levels segments; utils/mt19937_jump.npz holds 63 of them for 39,936-word segments).  seg_states: workspace of nerf_amd_mt19937_segments(next, n,
  * seg_words) * 624 words.  Values and final state identical to nerf_amd_mt19937_uniform. */
 int64_t nerf_amd_mt19937_segments(int next, int64_t n, int64_t seg_words);
 int nerf_amd_mt19937_uniform_par(const uint32_t* state624, int next, float* out, int64_t n,

@@ -87,7 +87,7 @@ _jump = {}
 
 
 def _jump_polys(device):
-    """(polys [levels, 624] on ``device``, levels, seg_words, short_polys [15, 624], short_seg_words) from
+    """(polys [levels, 624] on ``device``, levels, seg_words, short_polys [63, 624], short_seg_words) from
     utils/mt19937_jump.npz, or None."""
     key = str(device)
     if key not in _jump:
@@ -110,12 +110,10 @@ def _launch_uniform(words_dev, next0, out, n, state_out, device):
     if jp is not None:
         polys, levels, seg_words, short, short_words = jp
         S = int(lib.nerf_amd_mt19937_segments(int(next0), int(n), seg_words))
-        if S == 1:
-            # shorter than one long segment (a training batch): the finer cut, all start states in one launch
-            S = int(lib.nerf_amd_mt19937_segments(int(next0), int(n), short_words))
-            polys, levels, seg_words = short, -int(short.shape[0]), short_words
-            if S > 1 - levels:
-                S = 1
+        S_short = int(lib.nerf_amd_mt19937_segments(int(next0), int(n), short_words))
+        if S_short <= 1 + int(short.shape[0]):
+            # a training batch, the reference's test batch: the finer cut, all start states in ONE jump launch
+            S, polys, levels, seg_words = S_short, short, -int(short.shape[0]), short_words
         if 1 < S <= ((1 << levels) if levels > 0 else 1 - levels):
             ws = torch.empty((S, _N), dtype=torch.int32, device=device)
             _lib.check(lib.nerf_amd_mt19937_uniform_par(_lib.ptr(words_dev), int(next0), _lib.ptr(out), int(n),

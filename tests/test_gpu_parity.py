@@ -747,7 +747,9 @@ def test_reference_rand_is_torch_rand(dev, oracle):
     saved = torch.get_rng_state()
     try:
         for seed, pre, shape in ((0, 0, (3, 5)), (1, 3, (7, 100)), (2, 623, (1, 5)), (3, 624, (13, 100)), (4, 100, (1, 624)),
-                                 # training-batch sizes: the finer cut, every start state in one jump launch (4 .. 16 segments)
+                                 # training-batch sizes, the reference's test batch: the finer cut, every start state in one
+                                 # jump launch (4 .. 64 segments; 19968 x 128 is exactly 64, 19969 x 128 the long cut again)
+                                 (17, 5, (16000, 128)),
                                  (5, 0, (1000, 128)), (6, 77, (4096, 64)), (7, 500, (300, 2080)), (12, 0, (4096, 128)),
                                  (13, 17, (4992, 128)), (14, 624, (5000, 128)), (15, 1, (39936 + 623, 1)), (16, 1, (39936 + 624, 1)),
                                  # several segments: jump-ahead start states + one workgroup per segment

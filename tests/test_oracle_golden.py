@@ -275,10 +275,10 @@ def test_mt19937_jump_polynomials():
     assert seg_words % 624 == 0 and z["polys"].shape == (10, 624)
     for m in (0, 5):
         assert np.array_equal(z["polys"][m], J.to_words(J.x_pow_mod(seg_words << m, phi)))
-    # the finer cut for draws shorter than one such segment: the polynomial of every multiple, j = 1 .. 15
+    # the finer cut for draws shorter than one such segment: the polynomial of every multiple, j = 1 .. 63
     short_words = int(z["short_seg_words"])
-    assert short_words % 624 == 0 and z["short_polys"].shape == (15, 624) and 16 * short_words == seg_words
-    for j in (1, 7, 15):
+    assert short_words % 624 == 0 and z["short_polys"].shape == (63, 624) and 16 * short_words == seg_words
+    for j in (1, 16, 63):
         assert np.array_equal(z["short_polys"][j - 1], J.to_words(J.x_pow_mod(short_words * j, phi)))
     rng = np.random.default_rng(3)
     s = rng.integers(0, 2 ** 32, size=624, dtype=np.uint64).astype(np.uint32)

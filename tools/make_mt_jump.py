@@ -12,7 +12,7 @@ F^i applied to the state is the window w_i .. w_{i+623}, hence
 phi is found with Berlekamp-Massey on one output bit (Python integers as bit vectors), g_J by
 square-and-multiply.  Polynomials for J = SEG_WORDS * 2^m, m = 0 .. M-1, are stored so that the
 start states of up to 2^M segments follow from the first by a doubling tree; for draws shorter than one
-such segment a finer cut is stored with the polynomial of every multiple (J = SHORT_SEG_WORDS * j, j = 1 .. 15).
+few such segments a finer cut is stored with the polynomial of every multiple (J = SHORT_SEG_WORDS * j, j = 1 .. 63).
 
 Everything here is checked again by tests/test_oracle_golden.py (phi recomputed, a jump compared
 with plain sequential generation)."""
@@ -25,11 +25,12 @@ DEG = 19937
 SEG_BLOCKS = 1024                      # a segment = 1024 blocks of 624 words = 638,976 draws
 SEG_WORDS = SEG_BLOCKS * N
 LEVELS = 10                            # up to 1024 segments (6.5e8 draws) per call
-# draws of a training batch (4096 rays x 64 .. 128 samples = 2.6e5 .. 5.2e5) fit ONE such segment: a second, finer cut
-# with the polynomial of every multiple stored, so that all start states follow from the first in ONE launch
+# the draws of a training batch (4096 rays x 64 .. 128 samples = 2.6e5 .. 5.2e5) fit ONE such segment, those of the
+# reference's test batch (16,000 rays x 128 = 2.0e6) four: a second, finer cut with the polynomial of every multiple
+# stored, so that all start states follow from the first in ONE launch
 SHORT_SEG_BLOCKS = 64                  # 39,936 draws
 SHORT_SEG_WORDS = SHORT_SEG_BLOCKS * N
-SHORT_COUNT = 15                       # x^(j * SHORT_SEG_WORDS), j = 1 .. 15: up to 16 segments = one long segment
+SHORT_COUNT = 63                       # x^(j * SHORT_SEG_WORDS), j = 1 .. 63: up to 64 segments = 2.56e6 draws
 
 
 def raw_words(state, nblocks):
