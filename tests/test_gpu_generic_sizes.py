@@ -117,6 +117,20 @@ def test_forward_any_size_vs_oracle(dev, oracle, Lp, Ld, H):
     assert net(torch.empty(0, 6, device=dev)).shape == (0, 4)
 
 
+def test_inference_in_chunks_is_the_same(dev, monkeypatch):
+    """Without gradients an image's worth of points goes through the layers chunk by chunk (bounded activations in HBM):
+    identical to one pass, ragged last chunk included."""
+    from nerf_simple_amd.utils import generic_mlp
+    net, _ = make(6, 2, 128, dev)
+    v = points(1000, seed=3).to(dev)
+    with torch.no_grad():
+        whole = net(v)
+        monkeypatch.setattr(generic_mlp, "INFERENCE_CHUNK", 300)
+        parts = net(v)
+    assert torch.equal(whole, parts)
+    assert net(v).requires_grad                      # with gradients: one pass, activations kept for the backward
+
+
 @pytest.mark.parametrize("Lp,Ld,H", SIZES[:4])
 def test_gradients_any_size_vs_oracle_autograd(dev, oracle, Lp, Ld, H):
     """Every parameter gradient of the hand-written backward against torch autograd through the oracle's forward."""
