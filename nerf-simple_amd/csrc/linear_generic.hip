@@ -37,8 +37,10 @@ struct LinArgs {
 };
 
 __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs a) {
-    __shared__ float As[TK][TM + 4];
-    __shared__ float Bs[TK][TN + 4];
+    // [row / column][k] with an odd row stride (17 words): the operand stores -- along k or along the row index, whichever
+    // is contiguous in memory -- and the fragment reads (16 rows x 4 k per wave-instruction) all touch 32 distinct banks
+    __shared__ float As[TM][TK + 1];
+    __shared__ float Bs[TN][TK + 1];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const long long i0 = (long long)blockIdx.x * TM, j0 = (long long)blockIdx.y * TN;
     const long long k_lo = (long long)blockIdx.z * a.k_chunk;
@@ -85,9 +87,9 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs a) {
     if (k_lo < k_hi) fetch(k_lo);
     for (long long k0 = k_lo; k0 < k_hi; k0 += TK) {
 #pragma unroll
-        for (int r = 0; r < RA; ++r) As[ak[r]][ai[r]] = ra[r];
+        for (int r = 0; r < RA; ++r) As[ai[r]][ak[r]] = ra[r];
 #pragma unroll
-        for (int r = 0; r < RB; ++r) Bs[bk[r]][bj[r]] = rb[r];
+        for (int r = 0; r < RB; ++r) Bs[bj[r]][bk[r]] = rb[r];
         __syncthreads();
         if (k0 + TK < k_hi) fetch(k0 + TK);        // the next step's loads fly under this step's MFMAs
 #pragma unroll
@@ -96,8 +98,8 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs a) {
             float af[2], bf[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                af[t] = As[kk][wi + 16 * t + (lane & 15)];
-                bf[t] = Bs[kk][wj + 16 * t + (lane & 15)];
+                af[t] = As[wi + 16 * t + (lane & 15)][kk];
+                bf[t] = Bs[wj + 16 * t + (lane & 15)][kk];
             }
 #pragma unroll
             for (int ti = 0; ti < 2; ++ti)
@@ -129,6 +131,35 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs a) {
             }
 }
 
+// The bias gradients -- B a single 1.0f with both strides 0, N = 1, A read along its contiguous index (sa_i == 1) -- are
+// column sums, not a GEMM: one thread per output row, coalesced loads, K split over blockIdx.y, float atomics.
+// (As a 64-wide MFMA tile with one live column they took a quarter of the exact training step.)
+__global__ __launch_bounds__(256) void colsum_f32_kernel(LinArgs a) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.M) return;
+    const long long k_lo = (long long)blockIdx.y * a.k_chunk;
+    const long long k_hi = k_lo + a.k_chunk < a.K ? k_lo + a.k_chunk : a.K;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    long long k = k_lo;
+    for (; k + 4 <= k_hi; k += 4) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long off = i + (k + r) * a.sa_k;
+            v[r] = a.A[off];
+            if (a.A_mask && !(a.A_mask[off] > 0.f)) v[r] = 0.f;
+        }
+        s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
+    }
+    for (; k < k_hi; ++k) {
+        const long long off = i + k * a.sa_k;
+        float v = a.A[off];
+        if (a.A_mask && !(a.A_mask[off] > 0.f)) v = 0.f;
+        s0 += v;
+    }
+    atomicAdd(a.C + i * a.ldc, ((s0 + s1) + (s2 + s3)) * a.B[0]);
+}
+
 }  // namespace
 
 extern "C" int nerf_amd_launch_linear_f32(const float* A, long long sa_i, long long sa_k, const float* A_mask, const float* B,
@@ -137,6 +168,13 @@ extern "C" int nerf_amd_launch_linear_f32(const float* A, long long sa_i, long l
     (void)hipGetLastError();
     if (M <= 0 || N <= 0) return 0;
     LinArgs a{A, sa_i, sa_k, A_mask, B, sb_k, sb_j, bias, C, ldc, M, N, K, K > 0 ? K : 1, flags, 0};
+    if (N == 1 && sb_k == 0 && sb_j == 0 && sa_i == 1 && K > 0 && flags == LIN_ACCUMULATE && !bias) {
+        a.k_chunk = (K + 32767) / 32768 > 256 ? (K + 32767) / 32768 : 256;      // many short chunks: enough loads in flight
+        const long long gy = (K + a.k_chunk - 1) / a.k_chunk, gxs = (M + 255) / 256;
+        if (gy > 65535 || gxs > 2147483647ll) return -1;
+        hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)gxs, (unsigned)gy), dim3(256), 0, stream, a);
+        return (int)hipGetLastError();
+    }
     const long long gx = (M + TM - 1) / TM, gy = (N + TN - 1) / TN;
     long long gz = 1;
     // few output tiles and a long reduction (weight / bias gradients over all points): split K, sum with atomics
