@@ -114,11 +114,14 @@ def flat_grad_view(params):
 
 def allreduce_flat_(flat, group=None):
     """In-place mean over the data-parallel replicas of ONE flat gradient vector (the fused
-    backward's 2.38 MB bucket): a single all-reduce, then a scale."""
+    backward's 2.38 MB bucket): a single all-reduce (RCCL reduces to the mean itself; gloo has no AVG: sum, then a scale)."""
     rank, world = world_info(group)
     if collectives_active(group):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-        flat /= world
+        if dist.get_backend(group) == "nccl":
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+            flat /= world
     return flat
 
 
