@@ -102,19 +102,36 @@ def _jump_polys(device):
     return _jump[key]
 
 
+def _segments(next0, n, seg_words):
+    """Segments of a draw of n numbers (nerf_amd_mt19937_segments): the first takes the block's unread words and
+    seg_words new ones, every further one seg_words."""
+    avail = _N - int(next0)
+    return 1 + -(-(n - avail - seg_words) // seg_words) if n > avail + seg_words else 1
+
+
+def segment_plan(next0, n, levels, seg_words, n_short, short_words):
+    """How a draw of n numbers is cut: (S, table, levels argument, segment words) with table 'short' (every start state
+    from state 0 in ONE jump launch: training batches, the reference's test batch), 'long' (doubling tree: images) or
+    None (one workgroup, S = 1)."""
+    S_short = _segments(next0, n, short_words)
+    if 1 < S_short <= 1 + n_short:
+        return S_short, "short", -n_short, short_words
+    S = _segments(next0, n, seg_words)
+    if 1 < S <= (1 << levels):
+        return S, "long", levels, seg_words
+    return 1, None, 0, 0
+
+
 def _launch_uniform(words_dev, next0, out, n, state_out, device):
     """nerf_amd_mt19937_uniform, or its multi-workgroup form when the draw spans several segments."""
     lib = _lib.lib()
     st = _lib.stream_ptr(device)
     jp = _jump_polys(device)
     if jp is not None:
-        polys, levels, seg_words, short, short_words = jp
-        S = int(lib.nerf_amd_mt19937_segments(int(next0), int(n), seg_words))
-        S_short = int(lib.nerf_amd_mt19937_segments(int(next0), int(n), short_words))
-        if S_short <= 1 + int(short.shape[0]):
-            # a training batch, the reference's test batch: the finer cut, all start states in ONE jump launch
-            S, polys, levels, seg_words = S_short, short, -int(short.shape[0]), short_words
-        if 1 < S <= ((1 << levels) if levels > 0 else 1 - levels):
+        long_polys, levels, seg_words, short, short_words = jp
+        S, table, levels, seg_words = segment_plan(next0, n, levels, seg_words, int(short.shape[0]), short_words)
+        if table is not None:
+            polys = short if table == "short" else long_polys
             ws = torch.empty((S, _N), dtype=torch.int32, device=device)
             _lib.check(lib.nerf_amd_mt19937_uniform_par(_lib.ptr(words_dev), int(next0), _lib.ptr(out), int(n),
                                                         _lib.ptr(state_out), _lib.ptr(polys), levels, seg_words,

@@ -363,3 +363,32 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     n, ver = out.stdout.decode().split()
     assert int(n) == len(syms) and int(ver) == 3
+
+
+def test_reference_jitter_segment_plan():
+    """How utils/host_rng cuts a torch.rand(B, N) draw into workgroups (no GPU needed): one workgroup up to 39,936 new
+    numbers behind the block's unread words, the one-launch jump form up to 64 short segments (training batches, the
+    reference's 16,000-ray test batch), the doubling tree of 638,976-number segments beyond (images); and the count
+    agrees with the library's own (nerf_amd_mt19937_segments)."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.host_rng import segment_plan, _segments
+    lib = _lib.lib()
+    long_words, short_words, levels, n_short = 1024 * 624, 64 * 624, 10, 63
+    for next0 in (0, 1, 333, 624):
+        avail = 624 - next0
+        for n in (0, 1, avail, avail + short_words, avail + short_words + 1, 4096 * 64, 4096 * 128, 16000 * 128,
+                  avail + 64 * short_words, avail + 64 * short_words + 1, 640000 * 128, 3 * long_words + 5):
+            for words in (long_words, short_words):
+                assert _segments(next0, n, words) == lib.nerf_amd_mt19937_segments(next0, n, words), (next0, n, words)
+            S, table, lv, words = segment_plan(next0, n, levels, long_words, n_short, short_words)
+            if n <= avail + short_words:
+                assert (S, table) == (1, None)
+            elif n <= avail + 64 * short_words:
+                assert table == "short" and lv == -63 and words == short_words and 2 <= S <= 64
+                assert avail + (S - 1) * short_words < n <= avail + S * short_words
+            else:
+                assert table == "long" and lv == levels and words == long_words and S >= 2
+                assert avail + (S - 1) * long_words < n <= avail + S * long_words
+    assert segment_plan(0, 4096 * 64, levels, long_words, n_short, short_words)[0] == 7
+    assert segment_plan(0, 16000 * 128, levels, long_words, n_short, short_words)[0] == 52
+    assert segment_plan(0, 640000 * 128, levels, long_words, n_short, short_words)[:2] == (129, "long")
