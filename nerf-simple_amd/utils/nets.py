@@ -132,12 +132,14 @@ class Nerf(nn.Module):
 
     def __init__(self, Lp=10, Ld=4, H=256, *, precision=None):
         super().__init__()
-        if not all(isinstance(x, int) for x in (Lp, Ld, H)) or Lp < 1 or Ld < 1 or H < 2:
+        import numbers
+        if not all(isinstance(x, numbers.Integral) for x in (Lp, Ld, H)) or Lp < 1 or Ld < 1 or H < 2:
             # (the reference's encoder concatenates an empty list at L = 0, utils/xyz.py:6-14; H // 2 = 0 has no colour head)
             raise RuntimeError(f"Nerf(Lp={Lp}, Ld={Ld}, H={H}): sizes must be integers with Lp, Ld >= 1 and H >= 2")
         # Nerf() = (10, 4, 256) -- the one shape the reference ever constructs (train.py:41, test.py:27) -- runs on the
         # fused kernels; any other size runs layer by layer in fp32 on the strided GEMM kernel (utils/generic_mlp.py):
         # same results as the reference module, `precision` has no effect there
+        Lp, Ld, H = int(Lp), int(Ld), int(H)
         self.Lp, self.Ld, self.H = Lp, Ld, H
         self.precision = precision or DEFAULT_PRECISION
         _lib.precision_code(self.precision)
