@@ -27,6 +27,8 @@ Fixtures:
                        render_nerf at Nf = 128, MSELoss, Adam, lr *= decay) on a synthetic two-view dataset: loss per
                        step, parameters at steps 1 / 10 / 60, validation MSE; the same for three more seeds (the
                        reference's own run-to-run spread); dataset.npz = the dataset's target colours
+  G9 sizes.npz         the reference's Nerf(Lp, Ld, H) at three other sizes (its constructor takes any): forward and
+                       backward on 300 points; the initial weights are rebuilt from the seed (checksums stored)
 
     python tests/golden/make_golden.py            # everything
     python tests/golden/make_golden.py g6c g8     # only the named fixtures
@@ -409,6 +411,37 @@ def g8_trajectory(rays_tab, gt_tab):
     save("trajectory.npz", **out)
 
 
+G9_SIZES = ((6, 2, 128), (3, 1, 40), (2, 3, 37))
+
+
+def g9_sizes():
+    """G9: the reference module at sizes other than its default (utils/nets.py:9-32 takes any): Nerf(Lp, Ld, H) built
+    under a fixed seed of torch's CPU generator (so the test can rebuild the same initial weights: per-tensor checksums
+    are stored, not the weights), heads scaled x4 for a non-trivial output, forward on 300 scene points, backward of a
+    fixed upstream gradient: outputs, per-tensor gradient norms, 16 x 16 corners / full biases."""
+    out = {"sizes": np.asarray(G9_SIZES)}
+    for i, (Lp, Ld, H) in enumerate(G9_SIZES):
+        torch.manual_seed(900 + i)
+        net = rnets.Nerf(Lp, Ld, H)
+        with torch.no_grad():
+            net.sigma_fc[0].weight.mul_(4.0)
+            net.color_fc[2].weight.mul_(4.0)
+        v = synthetic.points_in_scene(300, seed=13 + i)
+        g_out = torch.randn(300, 4, generator=torch.Generator().manual_seed(70 + i))
+        y = net.forward(v)
+        y.backward(g_out)
+        tag = f"{Lp}_{Ld}_{H}"
+        out[f"{tag}/v"], out[f"{tag}/g_out"], out[f"{tag}/out"] = np_(v), np_(g_out), np_(y)
+        for k, p_ in net.named_parameters():
+            w = p_.detach()
+            out[f"{tag}/init/{k}"] = np.asarray([float(w.double().sum()), float(w.double().abs().sum()), float(w.reshape(-1)[0]),
+                                                 float(w.reshape(-1)[-1])])
+            g = p_.grad.detach()
+            out[f"{tag}/gnorm/{k}"] = np.float64(g.double().norm())
+            out[f"{tag}/grad/{k}"] = np_(g if g.dim() == 1 else g[:16, :16])
+    save("sizes.npz", **out)
+
+
 def g7_camera():
     f = synthetic.focal_from_fov(100)
     d = rxyz.rays_single_cam([100, 100, f])
@@ -440,6 +473,8 @@ if __name__ == "__main__":
             g4_render(kind)
         if want("g5"):
             g5_image(kind)
+    if want("g9"):
+        g9_sizes()
     if want("g6"):
         g6_train()
     if want("g6b"):

@@ -202,3 +202,23 @@ def test_render_and_training_step_any_size(dev, oracle):
     from nerf_simple_amd.training import GraphedTrainStep
     with pytest.raises(RuntimeError, match="no packed weight image"):
         GraphedTrainStep(net2, fused, B, N)
+
+
+def test_other_sizes_golden_from_the_reference(dev, golden):
+    """G9 (captured by running the reference's own Nerf(Lp, Ld, H) at three sizes): the layer-by-layer path reproduces
+    its outputs and its gradients -- the module rebuilt from the fixture's seed, initial weights checked bit for bit."""
+    from test_oracle_golden import g9_module
+    g = golden("sizes.npz")
+    for i in range(len(g["sizes"])):
+        net, tag, _ = g9_module(g, i)
+        net = net.to(dev)
+        v, g_out = torch.from_numpy(g[f"{tag}/v"]).to(dev), torch.from_numpy(g[f"{tag}/g_out"]).to(dev)
+        out = net(v)
+        assert rel_err(out.detach(), torch.from_numpy(g[f"{tag}/out"])) <= REL, tag
+        out.backward(g_out)
+        for k, p in net.named_parameters():
+            grad = p.grad.cpu().numpy()
+            assert abs(np.linalg.norm(grad.astype(np.float64)) / float(g[f"{tag}/gnorm/{k}"]) - 1) <= 5 * REL, (tag, k)
+            ref = g[f"{tag}/grad/{k}"]
+            got = grad if grad.ndim == 1 else grad[:16, :16]
+            assert np.abs(got - ref).max() <= REL * max(float(np.abs(grad).max()), 1e-30), (tag, k)

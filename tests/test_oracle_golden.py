@@ -287,3 +287,49 @@ def test_mt19937_jump_polynomials():
     want = J.raw_words(s, blocks)[blocks * 624:(blocks + 1) * 624]
     got = J.apply_jump(s, g)
     assert np.array_equal(got[1:], want[1:]) and ((int(got[0]) ^ int(want[0])) & 0x80000000) == 0
+
+
+def g9_module(g, i):
+    """The module of fixture G9's i-th size, rebuilt as the reference built it: same seed of the CPU generator, same
+    constructor order (our Nerf creates its nn.Linear layers in the reference's order, so nn.Linear's default
+    initialisers draw the same numbers), heads x4 -- checked against the stored per-tensor checksums, bit for bit."""
+    import torch
+    from nerf_simple_amd.utils.nets import Nerf
+    Lp, Ld, H = (int(x) for x in g["sizes"][i])
+    saved = torch.get_rng_state()
+    try:
+        torch.manual_seed(900 + i)
+        net = Nerf(Lp, Ld, H)
+    finally:
+        torch.set_rng_state(saved)
+    with torch.no_grad():
+        net.sigma_fc[0].weight.mul_(4.0)
+        net.color_fc[2].weight.mul_(4.0)
+    tag = f"{Lp}_{Ld}_{H}"
+    for k, p in net.named_parameters():
+        w = p.detach()
+        got = np.asarray([float(w.double().sum()), float(w.double().abs().sum()), float(w.reshape(-1)[0]), float(w.reshape(-1)[-1])])
+        assert np.array_equal(got, g[f"{tag}/init/{k}"]), (tag, k)
+    return net, tag, (Lp, Ld, H)
+
+
+def test_g9_other_sizes(golden, oracle):
+    """G9: the reference's Nerf(Lp, Ld, H) at sizes other than its default.  Our constructor initialises such a module
+    exactly as the reference's does (same generator stream), and the oracle's forward / autograd at those sizes are the
+    reference's: outputs to 1e-6, gradient norms to 1e-5, corner slices to 2e-5 of the tensor's scale."""
+    import torch
+    g = golden("sizes.npz")
+    for i in range(len(g["sizes"])):
+        net, tag, (Lp, Ld, H) = g9_module(g, i)
+        sd = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+        v, g_out = torch.from_numpy(g[f"{tag}/v"]), torch.from_numpy(g[f"{tag}/g_out"])
+        out = oracle.nerf_forward(sd, v, Lp, Ld)
+        want = g[f"{tag}/out"]
+        assert np.abs(out.detach().numpy() - want).max() <= 1e-6 * max(1.0, np.abs(want).max()), tag
+        out.backward(g_out)
+        for k, p in sd.items():
+            grad = p.grad.numpy()
+            assert abs(np.linalg.norm(grad.astype(np.float64)) / float(g[f"{tag}/gnorm/{k}"]) - 1) <= 1e-5, (tag, k)
+            ref = g[f"{tag}/grad/{k}"]
+            got = grad if grad.ndim == 1 else grad[:16, :16]
+            assert np.abs(got - ref).max() <= 2e-5 * max(float(np.abs(grad).max()), 1e-30), (tag, k)
