@@ -328,6 +328,25 @@ def event_timed(fn, steps, warmup, dev):
     return e0.elapsed_time(e1) / steps
 
 
+TABLE_IMAGES = 25                      # 25 images of 800 x 800 = 16 M rays: the reference's lego table (num_train_imgs, configs/lego.yaml)
+
+
+def synthetic_ray_table(dev, rank=0, seed=100):
+    """The training set as the reference holds it (utils/dataload.py:114-129, train.py:33) -- rays_dataset['train'] [n,6]
+    and train_imgs [n,3], n = 25 x 800 x 800 = 16 M -- resident in HBM (0.58 GB): rays of 25 synthetic cameras on a ring
+    (generated on the device), random target colours."""
+    from nerf_simple_amd.utils import synthetic
+    from nerf_simple_amd.utils.dataload import RayGenerator
+    from nerf_simple_amd.utils.rendering import generate_rays
+    from nerf_simple_amd.utils.xyz import spherical_to_pose
+    cam = [H, W, synthetic.focal_from_fov(W)]
+    rays = torch.cat([generate_rays(torch.from_numpy(spherical_to_pose(4, -30, 360.0 * k / TABLE_IMAGES + 3.0 * rank)).float(), cam, dev)
+                      for k in range(TABLE_IMAGES)])
+    gen = torch.Generator(device=dev).manual_seed(seed + rank)
+    colours = torch.rand((rays.shape[0], 3), generator=gen, device=dev)
+    return RayGenerator({"train": rays}, {"train": colours}, cam)
+
+
 def aux_configs(dev, sd, rays_800):
     """The other BASELINE.json configurations, a few seconds each on this one GPU, through the C ABI / the same host
     objects the tests use.  Returns the ``aux`` object of the JSON line (PSNR of the bf16 render is added by the
@@ -402,25 +421,23 @@ def aux_configs(dev, sd, rays_800):
     # ---- config 5: the training step (train.py:47-57), replayed hipGraphs, at the sample count BASELINE names (64)
     #      and at the reference's own (Nf = 128, configs/lego.yaml:6)
     aux["c5"] = {}
-    pose5 = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
-    rays5 = camera_rays([pose5], [64, 64, synthetic.focal_from_fov(64)]).to(dev).contiguous()
-    gen = torch.Generator().manual_seed(100)
-    gt5 = torch.rand(TRAIN_RAYS, 3, generator=gen).to(dev)
+    rg = synthetic_ray_table(dev)
+    n_table = int(rg.rays_dataset["train"].shape[0])
     for N, steps in ((64, 600), (128, 300)):
         net = net_of("bf16", 0, "default")
-        stepper = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), TRAIN_RAYS, N, device_rng=True, seed=7)
-
-        def one():
-            stepper.step(rays5, gt5)                  # fresh jitter every step, drawn in the kernels
-
-        ms = event_timed(one, steps, 30, dev)
+        # the whole iteration of train.py:47-57 inside the replayed graphs: rg.select + the colour gather from the 16 M-row
+        # tables (a fresh batch every step), fresh jitter, forward, backward, Adam, re-pack
+        stepper = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), TRAIN_RAYS, N, device_rng=True, seed=7, rays_from=rg)
+        ms = event_timed(stepper.step, steps, 30, dev)
         P = TRAIN_RAYS * N
-        aux["c5"][f"N{N}"] = {"workload": f"config 5: train.py step, 4096 rays x {N} samples, bf16, FusedAdam, hipGraph replay, 1 GPU",
-                              "ms": ms, "ray_samples_per_s": P / (ms * 1e-3),
-                              "kernel": "nerf_mlp_bf16_16_kernel<true, true, false> + composite_backward_kernel + nerf_mlp_bwd_kernel + dw_gemm_kernel + adam_hyper_kernel + pack_train_kernel",
+        aux["c5"][f"N{N}"] = {"workload": f"config 5: train.py iteration, 4096 rays x {N} samples selected on the device from a "
+                                          f"{n_table}-ray table every step, bf16, FusedAdam, hipGraph replay, 1 GPU",
+                              "ms": ms, "ray_samples_per_s": P / (ms * 1e-3), "table_rays": n_table,
+                              "kernel": "select_scan_kernel + select_gather_kernel + nerf_mlp_bf16_16_kernel<true, true, false> + composite_backward_kernel + nerf_mlp_bwd_kernel + dw_gemm_kernel + adam_hyper_kernel + pack_train_kernel",
                               "step_mfma_frac": 3 * FLOP_PER_SAMPLE * P / (ms * 1e-3) / PEAK_BF16, "peak_tflops": PEAK_BF16 / 1e12,
                               "final_loss": float(stepper.loss), "steps": steps}
         del stepper, net
+    del rg
     return aux
 
 
@@ -569,16 +586,15 @@ def run_train(args):
     net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
     parallel.broadcast_parameters(net)
     opt = FusedAdam(net, lr=5e-4)
-    # fresh stratified jitter every step, drawn inside the kernels by the counter RNG (seed + step count from device
-    # memory: the replayed graphs carry no per-step argument); each rank's ray ids are offset so ranks draw differently
+    # the reference's training set shape, resident in HBM: 16 M rays + colours per rank (its own cameras and targets)
+    rg = synthetic_ray_table(dev, rank)
+    n_table = int(rg.rays_dataset["train"].shape[0])
+    # the whole iteration inside the replayed graphs: a fresh batch of 4096 rays selected from the table (rg.select + the
+    # colour gather, train.py:47-49) and fresh stratified jitter every step, both from the counter RNG (seed + step count
+    # in device memory: the replayed graphs carry no per-step argument); ray_id0 offsets each rank's draws
     stepper = GraphedTrainStep(net, opt, B, N, group=(dist.group.WORLD if multi else None), timing=multi,
                                buckets=int(os.environ.get("NERF_BENCH_BUCKETS", "1")), device_rng=True, seed=1234,
-                               ray_id0=rank * B)
-    # synthetic batch: 4096 rays of a 64x64 camera on this rank's own azimuth, random targets
-    pose = torch.from_numpy(spherical_to_pose(4, -30, 20.0 * rank)).float()
-    rays = camera_rays([pose], [64, 64, synthetic.focal_from_fov(64)]).to(dev).contiguous()
-    gen = torch.Generator().manual_seed(100 + rank)
-    gt = torch.rand(B, 3, generator=gen).to(dev)
+                               ray_id0=rank * B, rays_from=rg)
     decay = lr_decay_factor(5e-4, 5e-5, 10000)              # reference configs/lego.yaml lr_init / lr_final shape
     it = [0]
 
@@ -588,7 +604,7 @@ def run_train(args):
         if record and not timed[0]:
             timed[0] = True
             stepper.reset_timing()                  # the exchange times are of the timed steps only
-        stepper.step(rays, gt, decay=decay)
+        stepper.step(decay=decay)
         it[0] += 1
 
     elapsed = timed_loop(step, args, dist, dev, world)
@@ -626,6 +642,9 @@ def run_train(args):
             "config": {"workload": "train.py step: 4096 rays x 64 samples per GPU, bf16, FusedAdam, hipGraph replay "
                                    "(BASELINE config 5)",
                        "jitter": "fresh per step, device counter RNG inside the timed step",
+                       "batch": f"fresh per step: rg.select + colour gather (train.py:47-49) from a {n_table}-ray table in HBM, "
+                                "inside the timed step (first two nodes of the replayed graph)",
+                       "table_rays": n_table,
                        "rays_per_gpu": B, "samples_per_ray": N, "global_batch_rays": B * world,
                        "parallelism": f"data-parallel x{world}" + (" + all_reduce of the flat 2.38 MB gradient" if multi else "")},
             "ranks": seen, "final_loss": loss,

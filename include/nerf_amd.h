@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 3
+#define NERF_AMD_ABI_VERSION 4
 
 /* error codes */
 #define NERF_AMD_EINVAL   (-1)   /* bad argument (null pointer, negative size, ...) */
@@ -349,6 +349,32 @@ int64_t nerf_amd_mt19937_segments(int next, int64_t n, int64_t seg_words);
 int nerf_amd_mt19937_uniform_par(const uint32_t* state624, int next, float* out, int64_t n,
                                  uint32_t* state_out624, const uint32_t* polys, int levels,
                                  int64_t seg_words, uint32_t* seg_states, void* stream);
+
+/* ---- ray selection: RayGenerator.select + the ground-truth gather, reference utils/dataload.py:141-153, train.py:47-49 ---- */
+/* The raw 32-bit outputs of the same generator (at::mt19937's random()): what `torch.randperm(n)` (dataload.py:151) draws
+ * its swap positions from.  Arguments as nerf_amd_mt19937_uniform; state_out624 may be NULL. */
+int nerf_amd_mt19937_raw(const uint32_t* state624, int next, uint32_t* out, int64_t n,
+                         uint32_t* state_out624, void* stream);
+/* HOST function (no GPU): h_poly624 = x^(624 * blocks) mod phi over GF(2), phi = the characteristic polynomial of MT19937's
+ * one-word step (h_phi624: 624 little-endian words, `phi` of utils/mt19937_jump.npz).  ~0.1 s; one per table size. */
+int nerf_amd_mt19937_jump_poly(int64_t blocks, const uint32_t* h_phi624, uint32_t* h_poly624);
+/* state_out624 = the generator's state words (1 + q) blocks after state624's block, poly624 = x^(624 q) mod phi on the
+ * device: where torch.randperm(n) leaves the generator after its n - 1 draws, of which nerf_amd_select_rays looks at the
+ * first B only.  All 32 bits of all 624 words are torch's.  One launch of 16 workgroups (~85 us). */
+int nerf_amd_mt19937_advance(const uint32_t* state624, const uint32_t* poly624, uint32_t* state_out624, void* stream);
+/* ray_ids = torch.randperm(n)[:B]; rays = table[ray_ids]; gt = colours[ray_ids]   (dataload.py:150-153, train.py:49) with
+ * table[n,6] and colours[n,3] resident in HBM.  ids_out[B] (int64, as torch's), rays_out[B,6], gt_out[B,3]: any may be NULL.
+ * The permutation prefix is the exact forward Fisher-Yates prefix of torch's CPU randperm (csrc/select.hip), from
+ *   draws != NULL: draws[i], i < min(B, n-1): the generator's next 32-bit outputs (nerf_amd_mt19937_raw) -- the
+ *                  reference's own ray_ids for the generator's state; seed / seed_mem ignored;
+ *   draws == NULL: the counter RNG keyed by seed (+ *seed_mem if seed_mem != NULL: a uint64 in DEVICE memory read when the
+ *                  kernel runs, so a launch captured into a hipGraph selects a fresh batch at every replay).
+ * B <= n < 2^32 / 20 (beyond, torch.randperm is another algorithm: NERF_AMD_EUNSUP).  workspace: nerf_amd_select_workspace_bytes(B).
+ * Two launches, no atomics on global memory, deterministic. */
+int64_t nerf_amd_select_workspace_bytes(int64_t B);
+int nerf_amd_select_rays(const uint32_t* draws, uint64_t seed, const uint64_t* seed_mem, int64_t n, int64_t B,
+                         const float* table, const float* colours, float* rays_out, float* gt_out, int64_t* ids_out,
+                         void* workspace, void* stream);
 
 /* The same update with the step-dependent scalars in DEVICE memory: hyper[6] = {lr, beta1,
  * beta2, eps, 1 - beta1^step, sqrt(1 - beta2^step)} (fp32).  The launch carries no per-step

@@ -80,6 +80,11 @@ _SIGNATURES = {
     "nerf_amd_mt19937_segments": (_i64, [_i32, _i64, _i64]),
     "nerf_amd_mt19937_uniform_par": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _i64, _vp, _vp]),
     "nerf_amd_adam_step_hyper": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "nerf_amd_mt19937_raw": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
+    "nerf_amd_mt19937_jump_poly": (_i32, [_i64, _vp, _vp]),
+    "nerf_amd_mt19937_advance": (_i32, [_vp, _vp, _vp, _vp]),
+    "nerf_amd_select_workspace_bytes": (_i64, [_i64]),
+    "nerf_amd_select_rays": (_i32, [_vp, _u64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nerf_amd_linear_f32": (_i32, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _u32, _vp]),
     "nerf_amd_render_forward": (_i32, [_vp, _vp, _vp, _vp, _i32, _u32, _u64, _i64,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
@@ -112,7 +117,7 @@ def lib():
                 for name, (res, args) in _SIGNATURES.items():
                     fn = getattr(h, name)          # AttributeError if an export is missing
                     fn.restype, fn.argtypes = res, args
-                if h.nerf_amd_abi_version() != 3:
+                if h.nerf_amd_abi_version() != 4:
                     raise RuntimeError("libnerf_amd.so ABI version mismatch")
                 _lib = h
     return _lib

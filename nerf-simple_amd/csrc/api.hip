@@ -35,6 +35,11 @@ int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, 
 int nerf_amd_launch_mt19937_uniform(const uint32_t*, int, float*, long long, uint32_t*, hipStream_t);
 int nerf_amd_launch_mt19937_uniform_par(const uint32_t*, int, float*, long long, uint32_t*, const uint32_t*, int, long long,
                                         uint32_t*, hipStream_t);
+int nerf_amd_launch_mt19937_raw(const uint32_t*, int, uint32_t*, long long, uint32_t*, hipStream_t);
+int nerf_amd_launch_mt19937_advance(const uint32_t*, const uint32_t*, uint32_t*, hipStream_t);
+int nerf_amd_launch_select_rays(const uint32_t*, unsigned long long, const unsigned long long*, long long, long long, const float*,
+                                const float*, float*, float*, long long*, void*, hipStream_t);
+int nerf_amd_host_mt19937_jump_poly(long long, const uint32_t*, uint32_t*);
 int nerf_amd_launch_adam_hyper(float*, const float*, float*, float*, long long, const float*, hipStream_t);
 int nerf_amd_launch_linear_f32(const float*, long long, long long, const float*, const float*, long long, long long, const float*,
                                float*, long long, long long, long long, long long, int, hipStream_t);
@@ -53,8 +58,10 @@ inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 // the jitter arguments of every rays-mode entry point: explicit u / ts, the counter RNG, or the counter RNG with its
 // seed offset in device memory (then `u` is that address)
 inline bool bad_jitter(uint32_t flags, const float* u, const float* tbins) {
+    if (flags & ~(NERF_AMD_TS_GIVEN | NERF_AMD_DEVICE_RNG | NERF_AMD_SEED_IN_MEMORY)) return true;     // unknown bits
     if (flags & NERF_AMD_SEED_IN_MEMORY) {
         if (!(flags & NERF_AMD_DEVICE_RNG) || (flags & NERF_AMD_TS_GIVEN) || !u) return true;
+        if (reinterpret_cast<uintptr_t>(u) & 7) return true;                   // the kernels load it as one 64-bit word
     } else if (!(flags & NERF_AMD_DEVICE_RNG) && !u) {
         return true;
     }
@@ -374,6 +381,7 @@ int nerf_amd_sample_pdf(const float* ts, const float* w, const float* u, uint32_
     if (B == 0) return 0;
     if (Nc < 3 || Nc > 256 || Nc + Nf > 512) return NERF_AMD_EUNSUP;
     if (!ts || !w || !ts_out) return NERF_AMD_EINVAL;
+    if (flags & ~NERF_AMD_DEVICE_RNG) return NERF_AMD_EINVAL;
     if (!(flags & NERF_AMD_DEVICE_RNG) && !u && Nf > 0) return NERF_AMD_EINVAL;
     return nerf_amd_launch_sample_pdf(ts, w, u, ts_out, B, Nc, Nf, seed, ray_id0,
                                       (flags & NERF_AMD_DEVICE_RNG) ? 1 : 0, S(stream));
@@ -393,7 +401,9 @@ int nerf_amd_render_hierarchical_forward(const float* h_pose, int H, int W, floa
     if (n_rays == 0) return 0;
     if (Nc < 3 || Nc > 256 || Nc + Nf > 512 || !fused_render(precision, Nc + Nf)) return NERF_AMD_EUNSUP;
     if (!workspace || !pixels || !packed_c || !packed_f || !tbins_c) return NERF_AMD_EINVAL;
-    if (flags & NERF_AMD_TS_GIVEN) return NERF_AMD_EINVAL;
+    // explicit jitter for both passes, or the counter RNG with its seed in the argument: the seed-in-memory form would
+    // need u_c to be that address, which this entry point does not offer (the coarse kernel would dereference it)
+    if (flags & ~NERF_AMD_DEVICE_RNG) return NERF_AMD_EINVAL;
     if (!(flags & NERF_AMD_DEVICE_RNG) && (!u_c || (!u_f && Nf > 0))) return NERF_AMD_EINVAL;
     char* ws = reinterpret_cast<char*>(workspace);
     float* rays = reinterpret_cast<float*>(ws);
@@ -539,6 +549,36 @@ int nerf_amd_mt19937_uniform_par(const uint32_t* state624, int next, float* out,
     if (levels >= 0 ? nseg > ((int64_t)1 << levels) : nseg > 1 - (int64_t)levels) return NERF_AMD_EUNSUP;
     return nerf_amd_launch_mt19937_uniform_par(state624, next, out, n, state_out624, polys, levels, seg_words, seg_states,
                                                S(stream));
+}
+
+int nerf_amd_mt19937_raw(const uint32_t* state624, int next, uint32_t* out, int64_t n, uint32_t* state_out624, void* stream) {
+    if (n < 0 || next < 0 || next > 624) return NERF_AMD_EINVAL;
+    if (!state624 || (n > 0 && !out)) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_mt19937_raw(state624, next, out, n, state_out624, S(stream));
+}
+
+int nerf_amd_mt19937_jump_poly(int64_t blocks, const uint32_t* h_phi624, uint32_t* h_poly624) {
+    if (blocks < 0 || blocks > ((int64_t)1 << 52) || !h_phi624 || !h_poly624) return NERF_AMD_EINVAL;
+    return nerf_amd_host_mt19937_jump_poly(blocks, h_phi624, h_poly624) == 0 ? 0 : NERF_AMD_EINVAL;
+}
+
+int nerf_amd_mt19937_advance(const uint32_t* state624, const uint32_t* poly624, uint32_t* state_out624, void* stream) {
+    if (!state624 || !poly624 || !state_out624 || state624 == state_out624) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_mt19937_advance(state624, poly624, state_out624, S(stream));
+}
+
+int64_t nerf_amd_select_workspace_bytes(int64_t B) { return B < 0 ? NERF_AMD_EINVAL : align_up(B * 12, 256); }
+
+int nerf_amd_select_rays(const uint32_t* draws, uint64_t seed, const uint64_t* seed_mem, int64_t n, int64_t B,
+                         const float* table, const float* colours, float* rays_out, float* gt_out, int64_t* ids_out,
+                         void* workspace, void* stream) {
+    if (n < 0 || B < 0 || B > n) return NERF_AMD_EINVAL;
+    if (n >= (int64_t)(0xffffffffu / 20u)) return NERF_AMD_EUNSUP;      // torch.randperm switches algorithm there
+    if (B == 0) return 0;
+    if (!workspace || (rays_out && !table) || (gt_out && !colours)) return NERF_AMD_EINVAL;
+    if (((uintptr_t)table & 7) || ((uintptr_t)rays_out & 7) || ((uintptr_t)seed_mem & 7)) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_select_rays(draws, seed, reinterpret_cast<const unsigned long long*>(seed_mem), n, B, table, colours,
+                                       rays_out, gt_out, reinterpret_cast<long long*>(ids_out), workspace, S(stream));
 }
 
 int nerf_amd_linear_f32(const float* A, int64_t sa_i, int64_t sa_k, const float* A_mask, const float* B, int64_t sb_k,

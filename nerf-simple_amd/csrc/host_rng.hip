@@ -31,20 +31,28 @@ __device__ __forceinline__ unsigned mt_twist(unsigned u, unsigned v) {
     const unsigned y = (u & 0x80000000u) | (v & 0x7fffffffu);
     return (y >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u);
 }
-__device__ __forceinline__ float mt_uniform(unsigned y) {
+__device__ __forceinline__ unsigned mt_temper(unsigned y) {
     y ^= y >> 11;
     y ^= (y << 7) & 0x9d2c5680u;
     y ^= (y << 15) & 0xefc60000u;
     y ^= y >> 18;
-    return (float)(y & 0xffffffu) * 5.9604644775390625e-08f;   // 2^-24, exact
+    return y;
 }
+// one draw as the consumer wants it: a float32 uniform (torch.rand) or the 32-bit output itself (at::mt19937's
+// random(), what torch.randperm takes its swap positions from)
+template <typename T> __device__ __forceinline__ T mt_draw(unsigned y);
+template <> __device__ __forceinline__ float mt_draw<float>(unsigned y) {
+    return (float)(mt_temper(y) & 0xffffffu) * 5.9604644775390625e-08f;   // 2^-24, exact
+}
+template <> __device__ __forceinline__ unsigned mt_draw<unsigned>(unsigned y) { return mt_temper(y); }
 
 // Segment b of the stream (blockIdx.x): b = 0 starts from the generator's state (unread words from
 // next0, then seg_words draws of new blocks); b >= 1 starts from seg_states[b] = that state advanced by
 // b * seg_words words (mt19937_jump_kernel), all of it unread-exhausted, and produces seg_words draws.
 // The last segment also hands back the state words.  A single segment (gridDim.x == 1) is the whole call.
+template <typename T>
 __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __restrict__ state_in0, int next00,
-                                                              float* __restrict__ out0, long long n_total,
+                                                              T* __restrict__ out0, long long n_total,
                                                               unsigned* __restrict__ state_out,
                                                               const unsigned* __restrict__ seg_states,
                                                               long long seg_words) {
@@ -56,7 +64,7 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __
     const unsigned* state_in = seg == 0 ? state_in0 : seg_states + (long long)seg * MT_N;
     const int next0 = seg == 0 ? next00 : MT_N;
     const long long off = seg == 0 ? 0 : avail0 + (long long)seg * seg_words;
-    float* out = out0 + off;
+    T* out = out0 + off;
     long long n = n_total - off;
     if (gridDim.x > 1) {
         const long long cap = seg == 0 ? avail0 + seg_words : seg_words;
@@ -100,12 +108,12 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __
             }
         } else {
             // this block's unread words [lo, 624) -> out[pos + (idx - lo)]
-            float* o = out + (pos - lo);
+            T* o = out + (pos - lo);
             const long long end = n - (pos - lo);      // idx must stay below this
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int idx = c + 256 * k;
-                if (idx < MT_N && idx >= lo && idx < end) o[idx] = mt_uniform(idx == MT_N - 1 ? last : old[idx]);
+                if (idx < MT_N && idx >= lo && idx < end) o[idx] = mt_draw<T>(idx == MT_N - 1 ? last : old[idx]);
             }
         }
         pos += MT_N - lo;
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __
         cur ^= 1;
         last = buf[cur][MT_M - 1] ^ mt_twist(last, buf[cur][0]);
     }
-    if (!last_seg) return;
+    if (!last_seg || !state_out) return;
     // the state words afterwards: the producers' registers when blocks were formed, else the input
     if (own) {
         state_out[t] = r0;
@@ -141,20 +149,26 @@ __global__ __launch_bounds__(512) void mt19937_uniform_kernel(const unsigned* __
 constexpr int MT_JUMP_BLOCKS = 33;                       // 33 * 624 = 20592 >= 19937 + 623 words
 constexpr int MT_DEG = 19937;
 
+constexpr int MT_JUMP_LDS_MAX = (MT_JUMP_BLOCKS + 2) * MT_N * (int)sizeof(unsigned);   // skip = 1: one more block
 constexpr int MT_JUMP_SPLIT = 16;                        // workgroups sharing one jump's convolution (624 = 16 * 39 words)
 
 // Jump j of a launch reads state src0 + j * src_step with polynomial polys[j * poly_step]: the doubling tree uses
 // (src_step, poly_step) = (1, 0) -- 2^m states advanced by the same distance -- and the one-launch form (0, 1): every
 // start state straight from state 0, each with its own polynomial.
+// skip = 1 convolves the sequence one block later: states[dst] = F^J (the block AFTER the source state).  Every word
+// the convolution then reads is a generated one, so all 32 bits of all 624 output words are the generator's own --
+// which a state that is handed back to torch's generator needs (nerf_amd_mt19937_advance); with skip = 0 the 31 low bits
+// of output word 0 depend on bits of the source's word 0 that are not part of its state (see above).
 __global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict__ states, const unsigned* __restrict__ polys,
-                                                           int src0, int dst0, int src_step, int poly_step) {
+                                                           int src0, int dst0, int src_step, int poly_step, int skip,
+                                                           const unsigned* __restrict__ src_ext) {
     // blockIdx.x = jump * MT_JUMP_SPLIT + part: the parts of a jump each rebuild the word sequence (cheap)
     // and convolve a slice of the polynomial, combining into the zero-initialised destination with atomicXor
     const int jump = blockIdx.x / MT_JUMP_SPLIT, part = blockIdx.x % MT_JUMP_SPLIT;
-    extern __shared__ unsigned w[];                       // [MT_JUMP_BLOCKS * 624] + the polynomial [624]
-    unsigned* gp = w + MT_JUMP_BLOCKS * MT_N;             // (624 dependent global loads cost 0.6 ms)
+    extern __shared__ unsigned w[];                       // [(MT_JUMP_BLOCKS + skip) * 624] + the polynomial [624]
+    unsigned* gp = w + (MT_JUMP_BLOCKS + skip) * MT_N;    // (624 dependent global loads cost 0.6 ms)
     const int t = threadIdx.x;
-    const unsigned* src = states + (long long)(src0 + jump * src_step) * MT_N;
+    const unsigned* src = src_ext ? src_ext : states + (long long)(src0 + jump * src_step) * MT_N;
     const unsigned* poly = polys + (long long)jump * poly_step * MT_N;
     for (int i = t; i < MT_N; i += 256) {
         w[i] = src[i];
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict_
     }
     __syncthreads();
     const bool own = t < MT_D, own3 = t + 2 * MT_D < MT_N - 1;
-    for (int b = 0; b < MT_JUMP_BLOCKS - 1; ++b) {
+    for (int b = 0; b < MT_JUMP_BLOCKS - 1 + skip; ++b) {
         const unsigned* old = w + b * MT_N;
         unsigned* nw = w + (b + 1) * MT_N;
         if (own) {
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict_
     for (int iw = part * PER; iw < (part + 1) * PER; ++iw) {
         const unsigned g = __builtin_amdgcn_readfirstlane(gp[iw]);
         if (g == 0) continue;
-        const unsigned* wi = w + iw * 32 + t;
+        const unsigned* wi = w + skip * MT_N + iw * 32 + t;
 #pragma unroll 8
         for (int b = 0; b < 32; ++b) {
             const unsigned m = 0u - ((g >> b) & 1u);
@@ -224,21 +238,21 @@ extern "C" int nerf_amd_launch_mt19937_uniform_par(const uint32_t* state_in, int
         if (e != hipSuccess) return (int)e;
         const int lds = (MT_JUMP_BLOCKS + 1) * MT_N * (int)sizeof(unsigned);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt19937_jump_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                                hipFuncAttributeMaxDynamicSharedMemorySize, MT_JUMP_LDS_MAX);
         if (e != hipSuccess) return (int)e;
         if (levels < 0) {                                           // every start state from state 0, one launch
             hipLaunchKernelGGL(mt19937_jump_kernel, dim3((unsigned)((S - 1) * MT_JUMP_SPLIT)), dim3(256), lds, stream, seg_states,
-                               polys, 0, 1, 0, 1);
+                               polys, 0, 1, 0, 1, 0, (const unsigned*)nullptr);
         } else {
             for (int m = 0; (1ll << m) < S; ++m) {                  // doubling tree over the segment start states
                 const long long have = 1ll << m;
                 const long long count = S - have < have ? S - have : have;
                 hipLaunchKernelGGL(mt19937_jump_kernel, dim3((unsigned)(count * MT_JUMP_SPLIT)), dim3(256), lds, stream,
-                                   seg_states, polys + (long long)m * MT_N, 0, (int)have, 1, 0);
+                                   seg_states, polys + (long long)m * MT_N, 0, (int)have, 1, 0, 0, (const unsigned*)nullptr);
             }
         }
     }
-    hipLaunchKernelGGL(mt19937_uniform_kernel, dim3((unsigned)S), dim3(512), 0, stream, state_in, next, out, n, state_out,
+    hipLaunchKernelGGL(mt19937_uniform_kernel<float>, dim3((unsigned)S), dim3(512), 0, stream, state_in, next, out, n, state_out,
                        seg_states, seg_words);
     return (int)hipGetLastError();
 }
@@ -246,7 +260,32 @@ extern "C" int nerf_amd_launch_mt19937_uniform_par(const uint32_t* state_in, int
 extern "C" int nerf_amd_launch_mt19937_uniform(const uint32_t* state_in, int next, float* out, long long n,
                                                uint32_t* state_out, hipStream_t stream) {
     (void)hipGetLastError();
-    hipLaunchKernelGGL(mt19937_uniform_kernel, dim3(1), dim3(512), 0, stream, state_in, next, out, n, state_out,
+    hipLaunchKernelGGL(mt19937_uniform_kernel<float>, dim3(1), dim3(512), 0, stream, state_in, next, out, n, state_out,
                        (const unsigned*)nullptr, 0ll);
+    return (int)hipGetLastError();
+}
+
+// The 32-bit outputs themselves (at::mt19937::operator(), CPUGeneratorImpl::random()): what torch.randperm draws.
+extern "C" int nerf_amd_launch_mt19937_raw(const uint32_t* state_in, int next, uint32_t* out, long long n,
+                                           uint32_t* state_out, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(mt19937_uniform_kernel<unsigned>, dim3(1), dim3(512), 0, stream, state_in, next, out, n, state_out,
+                       (const unsigned*)nullptr, 0ll);
+    return (int)hipGetLastError();
+}
+
+// state_out = the state words `1 + q` blocks after state_in's block, poly = x^(624 q) mod phi: what the generator holds
+// after a consumer has drawn through that many regenerations (torch.randperm(n): n - 1 draws, of which only the first
+// few are ever looked at -- csrc/select.hip).  state_out is an atomicXor target: zeroed here first.
+extern "C" int nerf_amd_launch_mt19937_advance(const uint32_t* state_in, const uint32_t* poly, uint32_t* state_out,
+                                               hipStream_t stream) {
+    (void)hipGetLastError();
+    hipError_t e = hipMemsetAsync(state_out, 0, MT_N * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return (int)e;
+    const int lds = (MT_JUMP_BLOCKS + 2) * MT_N * (int)sizeof(unsigned);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt19937_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            MT_JUMP_LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(mt19937_jump_kernel, dim3(MT_JUMP_SPLIT), dim3(256), lds, stream, state_out, poly, 0, 0, 0, 0, 1, state_in);
     return (int)hipGetLastError();
 }

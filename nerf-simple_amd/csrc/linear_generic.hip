@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(LinArgs a) {
             if (i0 + ai[r] < a.M && k0 + ak[r] < k_hi) {
                 const long long off = (i0 + ai[r]) * a.sa_i + (k0 + ak[r]) * a.sa_k;
                 v = a.A[off];
-                if (a.A_mask && !(a.A_mask[off] > 0.f)) v = 0.f;
+                if (a.A_mask && a.A_mask[off] <= 0.f) v = 0.f;      // torch threshold_backward: a NaN activation lets the gradient through
             }
             ra[r] = v;
         }
@@ -147,14 +147,14 @@ __global__ __launch_bounds__(256) void colsum_f32_kernel(LinArgs a) {
         for (int r = 0; r < 4; ++r) {
             const long long off = i + (k + r) * a.sa_k;
             v[r] = a.A[off];
-            if (a.A_mask && !(a.A_mask[off] > 0.f)) v[r] = 0.f;
+            if (a.A_mask && a.A_mask[off] <= 0.f) v[r] = 0.f;
         }
         s0 += v[0]; s1 += v[1]; s2 += v[2]; s3 += v[3];
     }
     for (; k < k_hi; ++k) {
         const long long off = i + k * a.sa_k;
         float v = a.A[off];
-        if (a.A_mask && !(a.A_mask[off] > 0.f)) v = 0.f;
+        if (a.A_mask && a.A_mask[off] <= 0.f) v = 0.f;      // torch threshold_backward: a NaN activation lets the gradient through
         s0 += v;
     }
     atomicAdd(a.C + i * a.ldc, ((s0 + s1) + (s2 + s3)) * a.B[0]);

@@ -134,7 +134,7 @@ __device__ __forceinline__ void chunk_barrier() {
 // ---- counter RNG: Philox-4x32-10 (Salmon et al. 2011), keyed by seed,
 // counter = global sample id.  One 32-bit word -> u in [0,1) with 24 bits, the
 // same granularity as torch.rand for float32.
-__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long ctr) {
+__device__ __forceinline__ unsigned philox_word(unsigned long long seed, unsigned long long ctr) {
     unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0x6e657266u, c3 = 0x616d6421u;
     unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
 #pragma unroll
@@ -144,7 +144,10 @@ __device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigne
         c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+    return c0;
+}
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long ctr) {
+    return (float)(philox_word(seed, ctr) >> 8) * (1.0f / 16777216.0f);
 }
 
 __device__ __forceinline__ float norm3(float x, float y, float z) {

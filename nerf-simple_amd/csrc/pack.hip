@@ -82,14 +82,18 @@ __global__ void pack_bias_kernel(const float* __restrict__ params, float* __rest
 }
 
 // the three images of a training step in ONE launch: forward bf16 image, its bias table, backward image.  The status
-// block is cleared here EXCEPT the weight-range word: that one is set by whichever workgroup meets the weight, and a
-// clear from another workgroup in the same kernel would land in no defined order (two XCDs' L2s writing one word).  It
-// therefore stays set from one training step to the next -- which is also what the weights do: Adam never heals a NaN /
-// inf weight -- until nerf_amd_pack_weights (new weights) clears it.
+// block is cleared here, and the weight-range word is DECIDED here, for exactly the weights packed now: a clear by one
+// workgroup and a set by another would land in no defined order (two XCDs' L2s writing one word), so the workgroups
+// collect their findings with device-scope atomics in two scratch words of the block and the last one to finish writes
+// the verdict (and leaves the scratch words zero for the next launch).  Weights repaired through the flat vector therefore
+// stop being flagged at the next re-pack.
+constexpr int PACK_SCRATCH_FLAG = 8, PACK_SCRATCH_COUNT = 9;       // words of the status block, zero between launches
 __global__ void pack_train_kernel(const float* __restrict__ params, __bf16* __restrict__ img, float* __restrict__ bias,
                                   __bf16* __restrict__ bwd, unsigned* __restrict__ status) {
-    if (blockIdx.x == 0 && threadIdx.x < B16_STATUS_BYTES / 4 && threadIdx.x != NERF_STATUS_WORD_WEIGHT_RANGE)
+    if (blockIdx.x == 0 && threadIdx.x < B16_STATUS_BYTES / 4 && threadIdx.x != NERF_STATUS_WORD_WEIGHT_RANGE &&
+        threadIdx.x != PACK_SCRATCH_FLAG && threadIdx.x != PACK_SCRATCH_COUNT)
         status[threadIdx.x] = 0u;
+    bool bad = false;
     const long long n_img = (long long)B16_WEIGHT_KIB * 512, n_bwd = (long long)BWD_WEIGHT_KIB * 512;
     const long long total = n_img + n_bwd + F32_BIAS_FLOATS;
     for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
@@ -103,7 +107,7 @@ __global__ void pack_train_kernel(const float* __restrict__ params, __bf16* __re
             const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
             const __bf16 cv = (__bf16)weight_at(params, L, 16 * rt + (lane & 15), src_col_b16(L, s, lane >> 4, j));
             img[e] = cv;
-            if (!(__builtin_fabsf((float)cv) < __builtin_inff())) status[NERF_STATUS_WORD_WEIGHT_RANGE] = 1u;   // as pack_b16_kernel
+            bad |= !(__builtin_fabsf((float)cv) < __builtin_inff());                                          // as pack_b16_kernel
         } else if (e < n_img + n_bwd) {
             const long long q = e - n_img;
             const int kib = (int)(q >> 9);
@@ -119,6 +123,15 @@ __global__ void pack_train_kernel(const float* __restrict__ params, __bf16* __re
             int L = 0;
             while (L + 1 < NUM_LAYERS && q >= f32_bias_off(L + 1)) ++L;
             bias[q] = bias_at(params, L, q - f32_bias_off(L));
+        }
+    }
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(&status[PACK_SCRATCH_FLAG], 1u);
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&status[PACK_SCRATCH_COUNT], 1u) == gridDim.x - 1) {          // every other workgroup has reported
+            __threadfence();
+            atomicExch(&status[NERF_STATUS_WORD_WEIGHT_RANGE], atomicExch(&status[PACK_SCRATCH_FLAG], 0u));
+            atomicExch(&status[PACK_SCRATCH_COUNT], 0u);
         }
     }
 }

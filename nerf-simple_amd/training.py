@@ -21,8 +21,8 @@ Precision: the fused training kernels exist in bf16 only (gradients need bf16's 
 would need loss scaling).  A module built with precision='bf16' or 'fp16' trains through them --
 ``precision`` selects the INFERENCE kernel only.  precision='fp32' trains EXACTLY, as the reference does
 (fp32 weights, activations and gradients: utils/generic_mlp.py, every nn.Linear and its backward on the
-strided fp32 MFMA GEMM nerf_amd_linear_f32, layer by layer): the slow, bit-faithful path -- its gradients match
-the reference's autograd to 1e-5 -- for checks and small problems; GraphedTrainStep is the fused bf16 step only.
+strided fp32 MFMA GEMM nerf_amd_linear_f32, layer by layer): the slow path, exact to fp32 round-off -- its gradients match
+the reference's autograd to 1e-5; long dW / db reductions are summed with float atomics, so the last bits vary from run to run -- for checks and small problems; GraphedTrainStep is the fused bf16 step only.
 """
 
 import torch
@@ -411,13 +411,20 @@ class GraphedTrainStep:
 
     ``step(rays, gt, u=None, decay=1.0)`` returns the loss as a 0-d device tensor (no sync).
 
+    ``rays_from`` = a ``utils.dataload.RayGenerator`` (tables resident in HBM): ``step()`` without rays then runs the
+    first lines of the reference's iteration itself (train.py:47-49: ``rg.select(mode, N=batch_size)`` and the
+    ``train_imgs[ray_ids]`` gather) on the device -- with ``device_rng=True`` as the first node of graph A (counter RNG
+    keyed by seed + step, a fresh batch at every replay, nothing on the host), otherwise from torch's CPU generator
+    continued on the device: the reference's own ``ray_ids`` (``self.ray_ids``) followed by its jitter draw, the
+    generator left exactly where the reference's iteration leaves it.
+
     ``check_every`` (default 16, 0 = never): every so many steps the forward's range flag is copied back without
     waiting; a later ``step`` raises FloatingPointError once such a copy shows non-finite values inside the network
     (NaN / inf weights or inputs: a diverged run) -- the reference would show a NaN loss there.
     """
 
     def __init__(self, net, optimizer, n_rays, N, *, tn=2, tf=6, group=None, timing=False, buckets=1,
-                 device_rng=False, seed=0, ray_id0=0, check_every=16):
+                 device_rng=False, seed=0, ray_id0=0, check_every=16, rays_from=None, select_mode="train"):
         from . import parallel
         from .optim import FusedAdam
         from .utils.rendering import _tbins
@@ -429,7 +436,8 @@ class GraphedTrainStep:
         self.net, self.opt, self.group = net, optimizer, group
         if buckets not in (1, 2):
             raise ValueError("buckets must be 1 (one all-reduce between the two graphs, the default) or 2 (overlapped)")
-        self.exchange = group is not None and parallel.collectives_active(group)
+        # group=None is the default process group, as everywhere in parallel.py (train_step(group=None) reduces over it too)
+        self.exchange = parallel.collectives_active(group)
         self.bucketed = self.exchange and buckets == 2
         self.timing, self._events = bool(timing), []
         self.device_rng, self.seed, self.ray_id0 = bool(device_rng), int(seed), int(ray_id0)
@@ -437,6 +445,15 @@ class GraphedTrainStep:
         self.B, self.N = int(n_rays), int(N)
         dev = optimizer.flat.device
         self.dev = dev
+        self.rays_from, self.select_mode = rays_from, select_mode
+        if rays_from is not None:
+            table = rays_from.rays_dataset[select_mode]
+            if select_mode not in rays_from.colours:
+                raise RuntimeError(f"rays_from has no colour table for mode {select_mode!r}")
+            if table.device != dev:
+                raise RuntimeError(f"rays_from lives on {table.device}, the module on {dev}")
+            if int(table.shape[0]) < self.B:
+                raise RuntimeError(f"a batch of {self.B} rays from a table of {int(table.shape[0])}")
         lib = _lib.lib()
         B, N_, P = self.B, self.N, self.B * self.N
         f32 = dict(dtype=torch.float32, device=dev)
@@ -458,6 +475,8 @@ class GraphedTrainStep:
         self.scratch = torch.empty(max(int(lib.nerf_amd_param_gradients_scratch_bytes(P)), 16), dtype=torch.uint8,
                                    device=dev)
         self.loss = torch.zeros((), **f32)
+        self.ray_ids = torch.zeros((B,), dtype=torch.int64, device=dev)        # rays_from: the batch's rows of the table
+        self._select_ws = torch.empty(max(int(lib.nerf_amd_select_workspace_bytes(B)), 256), dtype=torch.uint8, device=dev)
         import ctypes
         first, count = ctypes.c_int64(), ctypes.c_int64()
         self.buckets = []                                   # views of the flat gradient vector, in exchange order
@@ -488,6 +507,11 @@ class GraphedTrainStep:
         main = torch.cuda.current_stream(self.dev)
         side = self._side
         st, ss = ctypes_stream(main), ctypes_stream(side)
+        if self.rays_from is not None and self.device_rng:
+            # rg.select + the colour gather (train.py:47-49) as the first node: the step counter in device memory keys it
+            import ctypes
+            self.rays_from.launch(self.select_mode, B, None, self._select_seed(), ctypes.c_void_p(self.hyper.data_ptr() + 24),
+                                  self.rays, self.gt, self.ray_ids, stream=st, workspace=self._select_ws)
         side.wait_stream(main)
         if self.device_rng:
             # counter RNG; `u` = the address of this step's seed offset inside the hyper vector (int64 at float slot 6)
@@ -517,6 +541,10 @@ class GraphedTrainStep:
                                                       ptr(self.scratch), ptr(self.grads), P, bucket, st),
            "nerf_amd_param_gradients_finish_bucket")
 
+    def _select_seed(self):
+        # replicas (distinct ray_id0) must draw distinct batches
+        return (self.seed ^ (self.ray_id0 * 0x9E3779B97F4A7C15)) & 0xffffffffffffffff
+
     def _head_gradients(self):
         """The second launch of the bucketed form: the products of layers_0.* (bucket 2)."""
         P = self.B * self.N
@@ -539,9 +567,10 @@ class GraphedTrainStep:
 
     def _capture(self):
         with torch.cuda.device(self.dev):
-            # both images must exist (and be cached) before capture: packing allocates
-            self.net.packed_weights(_lib.BF16)
-            self.net.packed_weights(_lib.BF16_BWD)
+            # both images must exist (and be cached) before capture: packing allocates.  Their addresses are baked into
+            # the graphs, so this object owns them from here on (_own_images): the module's cache must never replace them
+            self._packed_fwd = self.net.packed_weights(_lib.BF16)
+            self._packed_bwd = self.net.packed_weights(_lib.BF16_BWD)
             self._set_hyper(1)
             params0 = self.opt.flat.clone()
             side = torch.cuda.Stream(self.dev)
@@ -565,37 +594,88 @@ class GraphedTrainStep:
             # capture executed nothing, and the warm-up did not touch the parameters
             assert torch.equal(self.opt.flat, params0)
             # a fresh pair of training images: whatever the warm-up left in their status words is gone
-            self.net.repack_from_flat(self.opt.flat)
+            self._own_images(force=True)
+
+    def _own_images(self, force=False):
+        """The two training images the graphs read and re-pack are THIS object's buffers.  If the parameters moved behind
+        the graphs' back since the last step (net.load_state_dict to restore a checkpoint, any in-place torch op: their
+        versions tell), the module's cache would pack NEW buffers on its next query and free these -- while every replay
+        still reads and rewrites them.  So: re-pack from the flat vector (the parameters are views of it) into the
+        captured buffers, as new weights (status words cleared), and put exactly these buffers back into the cache."""
+        from .utils.nets import _Packed
+        net, dev = self.net, self.dev
+        params = net._param_list()
+        stamp = tuple((p.data_ptr(), p._version) for p in params)
+        ents = [net._packed.get((dev, c)) for c in (_lib.BF16, _lib.BF16_BWD)]
+        bufs = (self._packed_fwd, self._packed_bwd)
+        if not force and all(e is not None and e.stamp == stamp and e.buf is b for e, b in zip(ents, bufs)):
+            return
+        off = 0
+        for p in params:                                   # FusedAdam made them views of its flat vector; still true?
+            if p.data_ptr() != self.opt.flat.data_ptr() + 4 * off:
+                raise RuntimeError("a parameter no longer lives in the optimizer's flat vector (its .data was replaced): "
+                                   "build a new FusedAdam and GraphedTrainStep")
+            off += p.numel()
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            for code, buf in zip((_lib.BF16, _lib.BF16_BWD), bufs):
+                _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(self.opt.flat), _lib.ptr(buf), code, _lib.stream_ptr(dev)),
+                           "nerf_amd_pack_weights")
+                net._packed[(dev, code)] = _Packed(stamp, buf)
+        net.drop_packed(dev, keep=(_lib.BF16, _lib.BF16_BWD))
 
     # ---- one iteration -------------------------------------------------------------
-    def step(self, rays, gt, u=None, decay=1.0):
+    def step(self, rays=None, gt=None, u=None, decay=1.0):
         from . import parallel
-        if rays.shape != self.rays.shape or gt.shape != self.gt.shape:
+        if (rays is None) != (gt is None):
+            raise RuntimeError("step(): rays and gt come together (or neither, with rays_from)")
+        if rays is None and self.rays_from is None:
+            raise RuntimeError("step() without rays needs GraphedTrainStep(..., rays_from=<utils.dataload.RayGenerator>)")
+        if rays is not None and (rays.shape != self.rays.shape or gt.shape != self.gt.shape):
             raise RuntimeError(f"GraphedTrainStep was captured for rays {tuple(self.rays.shape)}, gt {tuple(self.gt.shape)}")
         bad = self._watch.poll()
         if bad is not None:
             what = " and ".join(w for w, on in (("activations", bad[1]), ("weights", bad[2])) if on)
             raise FloatingPointError(f"non-finite values inside the network in training step {bad[0]} ({what}): "
                                      "NaN / inf weights or inputs, the run has diverged")
-        self.rays.copy_(rays, non_blocking=True)
-        self.gt.copy_(gt, non_blocking=True)
-        pending = None
-        if self.device_rng:
-            if u is not None:
-                raise RuntimeError("this GraphedTrainStep draws its jitter on the device (device_rng=True): u must be None")
-        else:
-            if u is None:
-                # the reference's one draw per call from torch's CPU generator, continued on the device; the generator is
-                # made current again (pending.finish: a wait for the generator kernel alone) once the whole step is
-                # enqueued behind it, so the host never waits for the previous step here
-                from .utils.host_rng import reference_rand
-                u, pending = reference_rand(self.B, self.N, self.dev)
-            self.u.copy_(u, non_blocking=True)
+        self._own_images()
+        select_in_graph = rays is None and self.device_rng
+        if rays is not None:
+            if self.rays_from is not None and self.device_rng:
+                raise RuntimeError("this GraphedTrainStep selects its rays inside the captured graph (rays_from, device_rng=True): "
+                                   "step() takes no rays")
+            self.rays.copy_(rays, non_blocking=True)
+            self.gt.copy_(gt, non_blocking=True)
+        session = None
         try:
+            if self.device_rng:
+                if u is not None:
+                    raise RuntimeError("this GraphedTrainStep draws its jitter on the device (device_rng=True): u must be None")
+            else:
+                from .utils import host_rng
+                if rays is None and host_rng.host_fallback():
+                    self.rays_from.select_batch(self.select_mode, self.B, out=(self.rays, self.gt, self.ray_ids))
+                elif rays is None:
+                    # the reference's iteration on torch's CPU stream, continued on the device: randperm(n)[:B] (the n - 1 - B
+                    # draws nobody looks at are jumped over), the two gathers, then -- same stream -- the jitter draw
+                    session = host_rng.GeneratorSession(self.dev)
+                    self.rays_from.select_from_session(session, self.select_mode, self.B, self.rays, self.gt, self.ray_ids,
+                                                       workspace=self._select_ws)
+                if u is None:
+                    # the reference's one draw per call from torch's CPU generator, continued on the device; the generator is
+                    # made current again (session.finish: a wait for the generator kernels alone) once the whole step is
+                    # enqueued behind it, so the host never waits for the previous step here
+                    if host_rng.host_fallback():
+                        self.u.copy_(torch.rand(self.B, self.N), non_blocking=False)
+                    else:
+                        session = session or host_rng.GeneratorSession(self.dev)
+                        session.rand(self.B, self.N, out=self.u)
+                else:
+                    self.u.copy_(u, non_blocking=True)
             return self._enqueue_step(decay)
         finally:
-            if pending is not None:
-                pending.finish()
+            if session is not None:
+                session.finish()
 
     def _enqueue_step(self, decay):
         from . import parallel
@@ -604,7 +684,7 @@ class GraphedTrainStep:
         self.graph_a.replay()
         if self.check_every and self.opt.step_count % self.check_every == 0:
             # behind the forward, in front of graph B's re-pack (which clears the flag for the next step)
-            self._watch.push(self.net.packed_weights(_lib.BF16), self.opt.step_count)
+            self._watch.push(self._packed_fwd, self.opt.step_count)
         if self.bucketed:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.timing else None
             if ev:

@@ -156,24 +156,119 @@ def _side_stream(device):
     return _side_streams[key]
 
 
-class _Pending:
-    """The state words coming back from the device; ``finish`` writes them into the generator."""
+class GeneratorSession:
+    """torch's CPU default generator continued on the device over CONSECUTIVE consumers -- the reference's training
+    iteration draws ``torch.randperm(n)`` (RayGenerator.select, utils/dataload.py:151) and then ``torch.rand(B, N)``
+    (render_nerf, utils/rendering.py:28) from the one stream.  The 624 state words go up once, every consumer leaves the
+    words it ends on in device memory for the next, the counters are kept here (at::mt19937's bookkeeping, ``_advance``),
+    and ``finish()`` -- to be called once everything that follows has been enqueued -- waits for the generator kernels
+    alone and writes words and counters back into torch's generator: values and generator state are torch's, bit for bit."""
 
-    def __init__(self, state, left, nxt, state_out, event):
-        self.state, self.left, self.nxt, self.state_out, self.event = state, left, nxt, state_out, event
+    def __init__(self, device):
+        self.device = device
+        self.state = torch.get_rng_state()
+        self.left, _seeded, self.nxt, words = _parse(self.state)
+        self.words_dev = torch.from_numpy(words.astype(np.uint32).view(np.int32)).to(device)
+        self.changed = False                     # the words on the device are no longer the generator's
+        self.event = None
+
+    def _first_unread(self):
+        return _N + 1 - int(self.left)           # 624 = block exhausted, as after seeding
+
+    def _moved(self, new_words, left, nxt, blocks):
+        if blocks > 0:
+            self.words_dev, self.changed = new_words, True
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(self.device))
+        self.left, self.nxt = left, nxt
+
+    def rand(self, B, N, out=None):
+        """``torch.rand(B, N).to(device)``: same values, same advance of the stream (``out``: a contiguous [B,N] buffer)."""
+        n = int(B) * int(N)
+        u = torch.empty((B, N), dtype=torch.float32, device=self.device) if out is None else out
+        if n == 0:
+            return u
+        left, nxt, blocks = _advance(self.left, self.nxt, n)
+        state_out = torch.empty(_N, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _launch_uniform(self.words_dev, self._first_unread(), u, n, state_out, self.device)
+            self._moved(state_out, left, nxt, blocks)
+        return u
+
+    def randperm_draws(self, n, B):
+        """The 32-bit outputs ``torch.randperm(n)`` takes its first min(B, n - 1) swap positions from (uint32 in an int32
+        tensor), with the stream moved past all n - 1 draws of the call (randperm_cpu, n < 2^32 / 20: one draw per
+        element but the last).  The draws nobody looks at are jumped over: x^(624 q) mod phi, one polynomial per table
+        size and block phase, made on first use (nerf_amd_mt19937_jump_poly) -- see csrc/select.hip."""
+        n, B = int(n), int(B)
+        total = max(n - 1, 0)
+        first = min(B, total)
+        lib = _lib.lib()
+        draws = torch.empty(max(first, 1), dtype=torch.int32, device=self.device)
+        if total == 0:
+            return draws[:0]
+        left, nxt, blocks = _advance(self.left, self.nxt, total)
+        with torch.cuda.device(self.device):
+            st = _lib.stream_ptr(self.device)
+            if blocks <= _SEQUENTIAL_BLOCKS:
+                # a short permutation: draw all of it (one workgroup, 0.6 us per block) and keep the head
+                everything = torch.empty(total, dtype=torch.int32, device=self.device)
+                state_out = torch.empty(_N, dtype=torch.int32, device=self.device)
+                _lib.check(lib.nerf_amd_mt19937_raw(_lib.ptr(self.words_dev), self._first_unread(), _lib.ptr(everything), total,
+                                                    _lib.ptr(state_out), st), "nerf_amd_mt19937_raw")
+                draws = everything[:first]
+            else:
+                _lib.check(lib.nerf_amd_mt19937_raw(_lib.ptr(self.words_dev), self._first_unread(), _lib.ptr(draws), first, None, st),
+                           "nerf_amd_mt19937_raw")
+                state_out = torch.empty(_N, dtype=torch.int32, device=self.device)
+                _lib.check(lib.nerf_amd_mt19937_advance(_lib.ptr(self.words_dev), _lib.ptr(advance_poly(blocks - 1, self.device)),
+                                                        _lib.ptr(state_out), st), "nerf_amd_mt19937_advance")
+            self._moved(state_out, left, nxt, blocks)
+        return draws[:first]
 
     def finish(self):
-        if self.state_out is None:
+        """Make torch's generator current (a wait for the generator kernels only, not for what was enqueued behind them)."""
+        if self.state is None:
             return
-        dev = self.state_out.device
-        side = _side_stream(dev)
-        with torch.cuda.stream(side):          # wait for the generator kernel only, not for the render behind it
-            side.wait_event(self.event)
-            host = self.state_out.to("cpu")
-        side.synchronize()
-        words = host.numpy().view(np.uint32)
+        words = None
+        if self.changed:
+            side = _side_stream(self.device)
+            with torch.cuda.stream(side):
+                side.wait_event(self.event)
+                host = self.words_dev.to("cpu")
+            side.synchronize()
+            words = host.numpy().view(np.uint32)
         torch.set_rng_state(_patched(self.state, self.left, self.nxt, words))
-        self.state_out = None
+        self.state = None
+
+
+_SEQUENTIAL_BLOCKS = 48                      # up to ~30,000 draws are cheaper drawn than jumped over (85 us)
+_phi = None
+_advance_polys = {}
+
+
+def advance_poly(q, device):
+    """x^(624 q) mod phi on ``device`` (624 words), cached: the jump of nerf_amd_mt19937_advance."""
+    global _phi
+    key = (int(q), str(device))
+    if key not in _advance_polys:
+        host_key = (int(q), "host")
+        if host_key not in _advance_polys:
+            if _phi is None:
+                path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "mt19937_jump.npz")
+                _phi = np.ascontiguousarray(np.load(path)["phi"].astype(np.uint32))
+            out = np.zeros(_N, dtype=np.uint32)
+            _lib.check(_lib.lib().nerf_amd_mt19937_jump_poly(int(q), _phi.ctypes.data, out.ctypes.data), "nerf_amd_mt19937_jump_poly")
+            _advance_polys[host_key] = out
+        _advance_polys[key] = torch.from_numpy(_advance_polys[host_key].view(np.int32)).to(device)
+    return _advance_polys[key]
+
+
+class _Done:
+    """A finished draw (host fallback)."""
+
+    def finish(self):
+        pass
 
 
 def reference_rand(B, N, device):
@@ -182,24 +277,16 @@ def reference_rand(B, N, device):
     Returns (u [B, N] on ``device``, pending): call ``pending.finish()`` once the launches that
     follow have been enqueued (it waits for the generator kernel and restores the generator)."""
     n = int(B) * int(N)
-    if os.environ.get("NERF_AMD_HOST_RNG") == "1" or n == 0 or not layout_ok():
-        return torch.rand(B, N).to(device), _Pending(None, 0, 0, None, None)
-    state = torch.get_rng_state()
-    left, _seeded, nxt, words = _parse(state)
-    new_left, new_next, blocks = _advance(left, nxt, n)
-    lib = _lib.lib()
-    u = torch.empty((B, N), dtype=torch.float32, device=device)
-    words_dev = torch.from_numpy(words.astype(np.uint32).view(np.int32)).to(device)
-    state_out = torch.empty(_N, dtype=torch.int32, device=device)
-    with torch.cuda.device(device):
-        # first unread word of the current block: 625 - left (624 = block exhausted, as after seeding)
-        _launch_uniform(words_dev, _N + 1 - int(left), u, n, state_out, device)
-        if blocks == 0:                         # the state words did not change: counters only, no read-back
-            torch.set_rng_state(_patched(state, new_left, new_next, None))
-            return u, _Pending(None, 0, 0, None, None)
-        event = torch.cuda.Event()
-        event.record(torch.cuda.current_stream(device))
-    return u, _Pending(state, new_left, new_next, state_out, event)
+    if host_fallback() or n == 0:
+        return torch.rand(B, N).to(device), _Done()
+    session = GeneratorSession(device)
+    return session.rand(B, N), session
+
+
+def host_fallback():
+    """The draws come from torch on the host (NERF_AMD_HOST_RNG=1, or a torch build whose generator layout is not the
+    one pinned by ``layout_ok``): the reference's own calls, by definition the same numbers."""
+    return os.environ.get("NERF_AMD_HOST_RNG") == "1" or not layout_ok()
 
 
 class ReferenceJitter:
@@ -214,8 +301,8 @@ class ReferenceJitter:
     def __init__(self, batch_rays, N, device):
         self.device, self.N = device, int(N)
         self.sizes = [int(b) for b in batch_rays]
-        self.fallback = os.environ.get("NERF_AMD_HOST_RNG") == "1" or not layout_ok() or not self.sizes
-        self.pending = _Pending(None, 0, 0, None, None)
+        self.fallback = host_fallback() or not self.sizes
+        self.pending = _Done()
         if self.fallback:
             return
         self.offsets, row = [], 0

@@ -307,11 +307,12 @@ def train_loop(sd, rays_table, gt_table, batch_size, N, num_iters, lr_init, lr_f
 # --------------------------------------------------------------------------
 # torch's CPU uniform stream (the jitter of reference utils/rendering.py:28-30), restated
 # --------------------------------------------------------------------------
-def mt19937_uniform(words, nxt, n):
+def mt19937_uniform(words, nxt, n, raw=False):
     """Continue at::mt19937 (ATen/core/MT19937RNGEngine.h) for n float32 uniforms
     (ATen/core/DistributionsHelper.h: one 32-bit output per draw, u = (y & 0xFFFFFF) * 2^-24).
     words: the 624 state words (uint32), nxt: first unread word of the current block (0..624).
-    Returns (u float32 [n], state words afterwards).  Pinned against torch.rand itself in
+    Returns (u float32 [n], state words afterwards); raw=True: the 32-bit outputs themselves (CPUGeneratorImpl::random(),
+    what torch.randperm draws).  Pinned against torch.rand / torch.randperm themselves in
     tests/test_oracle_golden.py; checker for csrc/host_rng.hip."""
     import numpy as np
     N_, M_ = 624, 397
@@ -328,7 +329,7 @@ def mt19937_uniform(words, nxt, n):
         y = y ^ ((y << np.uint32(15)) & np.uint32(0xefc60000))
         return y ^ (y >> np.uint32(18))
 
-    out = np.empty(n, dtype=np.float32)
+    out = np.empty(n, dtype=np.uint32 if raw else np.float32)
     k = 0
     while k < n:
         if nxt >= N_:
@@ -340,7 +341,65 @@ def mt19937_uniform(words, nxt, n):
             new[N_ - 1] = new[M_ - 1] ^ twist(mt[N_ - 1:N_], new[0:1])[0]
             mt, nxt = new, 0
         take = min(N_ - nxt, n - k)
-        out[k:k + take] = (temper(mt[nxt:nxt + take]) & np.uint32(0xffffff)).astype(np.float32) * np.float32(2.0 ** -24)
+        y = temper(mt[nxt:nxt + take])
+        out[k:k + take] = y if raw else (y & np.uint32(0xffffff)).astype(np.float32) * np.float32(2.0 ** -24)
         k += take
         nxt += take
     return out, mt
+
+
+# --------------------------------------------------------------------------
+# ray selection  (reference utils/dataload.py:141-153 RayGenerator.select, train.py:47-49)
+# --------------------------------------------------------------------------
+def randperm_prefix(n, B, draws):
+    """``torch.randperm(n)[:B]`` from the generator's next 32-bit outputs ``draws`` (the first min(B, n-1) of the n - 1
+    the call consumes).  The algorithm lives in torch, not in the reference (third-party: torch 2.10.0
+    ATen/native/TensorFactories.cpp randperm_cpu, n < 2^32/20): r = [0..n-1]; for i in 0..n-2: swap(r[i], r[i + random() % (n-i)]).
+    Sequential restatement over a sparse table of the touched positions; pinned against torch.randperm itself in
+    tests/test_oracle_golden.py (which also pins the reference's call site: G6c / G8 store the ray_ids of reference runs).
+    Checker for csrc/select.hip."""
+    moved, out = {}, []
+    for i in range(min(B, n)):
+        j = i + int(draws[i]) % (n - i) if i < n - 1 else i
+        vi, vj = moved.get(i, i), moved.get(j, j)
+        out.append(vj)
+        moved[j], moved[i] = vi, vj
+    return np.asarray(out, dtype=np.int64)
+
+
+def select(rays_table, colours, B, words, nxt):
+    """rg.select(mode, N=B) + the ground-truth gather (dataload.py:150-153, train.py:49) from the generator state
+    (words, nxt): (rays [B,6], gt [B,3], ray_ids [B] int64)."""
+    n = int(rays_table.shape[0])
+    first = min(B, max(n - 1, 0))
+    draws, _ = mt19937_uniform(words, nxt, first, raw=True)
+    ids = torch.from_numpy(randperm_prefix(n, B, draws))
+    return rays_table[ids, :], colours[ids, :].float(), ids
+
+
+def philox_word(seed, ctr):
+    """Philox-4x32-10 (Salmon et al. 2011) as csrc/nerf_device.h keys it: counter (ctr lo, ctr hi, 'nerf', 'amd!'), key =
+    seed; first output word.  numpy, vectorised over ctr.  The build's own counter RNG: no reference counterpart."""
+    ctr = np.asarray(ctr, dtype=np.uint64)
+    m32 = np.uint64(0xffffffff)
+    c0, c1 = ctr & m32, ctr >> np.uint64(32)
+    c2 = np.full_like(c0, 0x6e657266)
+    c3 = np.full_like(c0, 0x616d6421)
+    k0, k1 = np.uint64(int(seed) & 0xffffffff), np.uint64((int(seed) >> 32) & 0xffffffff)
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        n0, n2 = (p1 >> np.uint64(32)) ^ c1 ^ k0, (p0 >> np.uint64(32)) ^ c3 ^ k1
+        c1, c3, c0, c2 = p1 & m32, p0 & m32, n0, n2
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & m32, (k1 + np.uint64(0xBB67AE85)) & m32
+    return c0.astype(np.uint32)
+
+
+SELECT_KEY = 0x73656c6563743a31
+
+
+def select_ids_counter(n, B, seed, seed_offset=0):
+    """The ids nerf_amd_select_rays draws from the counter RNG: the same forward Fisher-Yates prefix with
+    z_i = philox_word((seed ^ SELECT_KEY) + seed_offset, i)."""
+    key = ((int(seed) ^ SELECT_KEY) + int(seed_offset)) & 0xffffffffffffffff
+    first = min(B, max(n - 1, 0))
+    return randperm_prefix(n, B, philox_word(key, np.arange(first, dtype=np.uint64)))

@@ -175,6 +175,7 @@ def run_trajectory(dev, golden, oracle, synthetic, mode, seed_index=0, precision
     from nerf_simple_amd.optim import FusedAdam
     from nerf_simple_amd.training import train_step, GraphedTrainStep
     from nerf_simple_amd.utils.rendering import render_nerf
+    from nerf_simple_amd.utils.dataload import RayGenerator
     g = golden("trajectory.npz")
     rays_tab, gt_tab = dataset_tables(golden, oracle, synthetic)
     B, N, K, decay = int(g["B"]), int(g["N"]), int(g["K"]), float(g["decay"])
@@ -196,18 +197,30 @@ def run_trajectory(dev, golden, oracle, synthetic, mode, seed_index=0, precision
         net = Nerf(precision=precision).to(dev)
         net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
         opt = FusedAdam(net, lr=5e-4)                       # torch.optim.Adam(net.parameters(), lr=5e-4), train.py:43
-        stepper = GraphedTrainStep(net, opt, B, N) if mode == "graphed" else None
+        # "*_select": the first two lines of the iteration (rg.select and the colour gather, train.py:47-49) run on the
+        # device too, from tables resident in HBM (utils/dataload.RayGenerator): nothing of the loop is left on the host
+        on_device = mode.endswith("_select")
+        rg = RayGenerator.from_tables(rays_tab, gt_tab, device=dev) if on_device else None
+        stepper = GraphedTrainStep(net, opt, B, N, rays_from=rg) if mode.startswith("graphed") else None
         losses, vals, snaps = [], [val_mse(net)], {}
         torch.manual_seed(seed)
         for i in range(K):
-            ids = torch.randperm(rays_tab.size(0))[:B]      # rg.select (utils/dataload.py:150-153), same CPU stream
-            rays, gt = rays_tab[ids].to(dev), gt_tab[ids].to(dev)
-            if i == 0:
-                assert np.array_equal(ids.numpy(), g["ray_ids0"])
-            if stepper is not None:
-                loss = stepper.step(rays, gt, decay=decay)   # jitter: the reference's torch.rand(B, N), continued on the device
+            if on_device and stepper is not None:
+                loss = stepper.step(decay=decay)             # select + gather + jitter: the reference's stream, on the device
+                ids = stepper.ray_ids
             else:
-                loss = train_step(net, opt, rays, gt, N, decay=decay)
+                if on_device:
+                    rays, ids = rg.select(mode="train", N=B)
+                    gt = rg.colours["train"][ids, :]
+                else:
+                    ids = torch.randperm(rays_tab.size(0))[:B]      # rg.select (utils/dataload.py:150-153), same CPU stream
+                    rays, gt = rays_tab[ids].to(dev), gt_tab[ids].to(dev)
+                if stepper is not None:
+                    loss = stepper.step(rays, gt, decay=decay)   # jitter: the reference's torch.rand(B, N), continued on the device
+                else:
+                    loss = train_step(net, opt, rays, gt, N, decay=decay)
+            if i == 0:
+                assert np.array_equal(ids.cpu().numpy(), g["ray_ids0"])
             losses.append(float(loss))
             if i + 1 in ckpts:
                 vals.append(val_mse(net))
@@ -248,7 +261,7 @@ def test_training_trajectory_exact_fp32(dev, golden, oracle, synthetic):
     assert max(perr.values()) <= EXACT_PARAM_RTOL, perr
 
 
-@pytest.mark.parametrize("mode", ["eager", "graphed"])
+@pytest.mark.parametrize("mode", ["eager", "graphed", "eager_select", "graphed_select"])
 def test_training_trajectory(dev, golden, oracle, synthetic, mode):
     """G8: 60 iterations of the reference's loop (train.py:45-57) with the fused bf16 kernels, same seed as the
     reference run -- so the same rays and the same jitter at every step, and torch's CPU generator ends at the same
@@ -314,7 +327,8 @@ def test_inference_after_graphed_steps_sees_new_weights(dev, golden, oracle, syn
             assert float((got - before[p]).abs().max()) > 1e-3, p      # and the weights did move
 
 
-def test_reference_loop_body_verbatim(dev, golden, oracle, synthetic):
+@pytest.mark.parametrize("tables", ["host", "device"])
+def test_reference_loop_body_verbatim(dev, golden, oracle, synthetic, tables):
     """The drop-in claim, literally: the statements of the reference's training loop (train.py:41-57) with only the
     import root swapped -- ``Nerf().cuda()``, ``nn.MSELoss()``, ``torch.optim.Adam(net.parameters(), lr=5e-4)``,
     ``render_nerf(rays.cuda(), net, params['Nf'])``, ``loss.backward()``, ``optimizer.step()``, the param_groups decay
@@ -337,10 +351,22 @@ def test_reference_loop_body_verbatim(dev, golden, oracle, synthetic):
         optimizer = torch.optim.Adam(net.parameters(), lr=5e-4)
         losses = []
         torch.manual_seed(seed)
+        if tables == "device":
+            # rg = RayGenerator(...) with its tables in HBM; train_imgs likewise: the loop's own first two statements
+            from nerf_simple_amd.utils.dataload import RayGenerator
+            rg = RayGenerator.from_tables(rays_tab, device=dev)
+            train_imgs = gt_tab.to(dev)
+        batch_size = params["batch_size"]
         for i in range(10):
-            ray_ids = torch.randperm(rays_tab.size(0))[:params["batch_size"]]            # rg.select(mode='train', N=batch_size)
-            rays = rays_tab[ray_ids, :]
-            gt_colors = gt_tab[ray_ids, :].float().cuda()
+            if tables == "device":
+                rays, ray_ids = rg.select(mode='train', N=batch_size)
+                gt_colors = train_imgs[ray_ids, :].float().cuda()
+                if i == 0:
+                    assert np.array_equal(ray_ids.cpu().numpy(), g["ray_ids0"])
+            else:
+                ray_ids = torch.randperm(rays_tab.size(0))[:params["batch_size"]]            # rg.select(mode='train', N=batch_size)
+                rays = rays_tab[ray_ids, :]
+                gt_colors = gt_tab[ray_ids, :].float().cuda()
             optimizer.zero_grad()
             rgb, depth, alpha, acc, w = render_nerf(rays.cuda(), net, params["Nf"])
             loss = criterion(rgb, gt_colors)

@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,7 +39,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_introspection(lib):
-    assert lib.nerf_amd_abi_version() == 3
+    assert lib.nerf_amd_abi_version() == 4
     assert lib.nerf_amd_param_count() == 595844
     # 16-bit images: weights, bias table, 256-byte status block (the fp16 range guard's sticky flags)
     assert lib.nerf_amd_packed_bytes(1) == lib.nerf_amd_packed_bytes(2) == 1172 * 1024 + 2464 * 4 + 256
@@ -227,6 +228,59 @@ def test_abi_argument_errors(lib):
     assert lib.nerf_amd_query_points(one, null, one, 0, 0, 0, one, null, 4, 8, null) == EINVAL        # no jitter
     assert lib.nerf_amd_query_points(null, null, null, 0, 0, 0, null, null, 0, 8, null) == 0           # no rays: nothing to do
     assert lib.nerf_amd_param_gradients_finish_bucket(one, one, one, one, one, one, 16, 3, null) == EINVAL   # buckets are 0, 1, 2
+    # flags: unknown bits, and the seed-in-memory form (its address must be 8-byte aligned; the hierarchical entry has no such form)
+    assert lib.nerf_amd_render_forward(one, one, one, one, 1, 8, 0, 0, one, one, null, one, null, one, 4, 8, null) == EINVAL
+    assert lib.nerf_amd_render_forward(one, ctypes.c_void_p(20), one, one, 1, 6, 0, 0, one, one, null, one, null, one, 4, 8, null) == EINVAL
+    assert lib.nerf_amd_render_hierarchical_forward(one, 8, 8, ctypes.c_float(5.0), 0, 64, null, null, one, one, one, 1, 6, 0,
+                                                    one, one, 16, 16, null) == EINVAL
+    assert lib.nerf_amd_render_hierarchical_forward(one, 8, 8, ctypes.c_float(5.0), 0, 64, one, one, one, one, one, 1, 8, 0,
+                                                    one, one, 16, 16, null) == EINVAL
+    assert lib.nerf_amd_sample_pdf(one, one, one, 4, 0, 0, one, 4, 16, 8, null) == EINVAL
+    # ray selection (RayGenerator.select): B <= n < 2^32 / 20, aligned tables
+    assert lib.nerf_amd_select_rays(null, 0, null, 10, 11, one, one, one, one, one, one, null) == EINVAL       # B > n
+    assert lib.nerf_amd_select_rays(null, 0, null, 2 ** 32 // 20, 16, one, one, one, one, one, one, null) == EUNSUP
+    assert lib.nerf_amd_select_rays(null, 0, null, 10, 0, null, null, null, null, null, null, null) == 0       # nothing to select
+    assert lib.nerf_amd_select_rays(null, 0, null, 100, 16, one, one, one, one, one, null, null) == EINVAL     # no workspace
+    assert lib.nerf_amd_select_rays(null, 0, null, 100, 16, ctypes.c_void_p(20), one, one, one, one, one, null) == EINVAL   # rows are read 8 bytes at a time
+    assert lib.nerf_amd_select_rays(null, 0, null, 100, 16, null, one, one, one, one, one, null) == EINVAL     # rays out without a table
+    assert lib.nerf_amd_select_workspace_bytes(4096) == 49152
+    assert lib.nerf_amd_mt19937_raw(null, 0, one, 4, null, null) == EINVAL
+    assert lib.nerf_amd_mt19937_advance(one, one, one, null) == EINVAL                                          # in place
+    assert lib.nerf_amd_mt19937_jump_poly(-1, one, one) == EINVAL
+
+
+def test_jump_polynomial_on_the_host(lib):
+    """nerf_amd_mt19937_jump_poly (C++, host): x^(624 q) mod phi equals tools/make_mt_jump.py's big-integer
+    square-and-multiply for small and table-sized q, a wrong phi is refused, and the polynomial does what it is for:
+    the GF(2) convolution over the raw word sequence lands on the state q blocks later (sequential generation)."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("make_mt_jump", os.path.join(ROOT, "tools", "make_mt_jump.py"))
+    J = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(J)
+    z = np.load(os.path.join(ROOT, "nerf-simple_amd", "utils", "mt19937_jump.npz"))
+    phi_words = np.ascontiguousarray(z["phi"].astype(np.uint32))
+    phi = int.from_bytes(phi_words.astype("<u4").tobytes(), "little")
+
+    def poly(q):
+        out = np.zeros(624, dtype=np.uint32)
+        assert lib.nerf_amd_mt19937_jump_poly(q, phi_words.ctypes.data, out.ctypes.data) == 0
+        return out
+
+    assert poly(0)[0] == 1 and not poly(0)[1:].any()
+    for q in (1, 2, 31, 32, 33, 300, (16_000_000 - 1) // 624):
+        assert np.array_equal(poly(q), J.to_words(J.x_pow_mod(624 * q, phi))), q
+    t0 = time.time()
+    poly((64_000_000 - 1) // 624)
+    assert time.time() - t0 < 5.0
+    bad = phi_words.copy()
+    bad[623] = 0                                           # degree < 19937: not the characteristic polynomial
+    assert lib.nerf_amd_mt19937_jump_poly(5, bad.ctypes.data, np.zeros(624, dtype=np.uint32).ctypes.data) == -1
+    rng = np.random.default_rng(4)
+    s = rng.integers(0, 2 ** 32, size=624, dtype=np.uint64).astype(np.uint32)
+    seq = J.raw_words(s, 41)
+    got = J.apply_jump(seq[624:2 * 624], poly(39))         # skip = 1: from the block AFTER the state, every word generated
+    assert np.array_equal(got, seq[40 * 624:41 * 624])     # all 32 bits of all 624 words (nerf_amd_mt19937_advance)
 
 
 def test_checkpoint_roundtrip(tmp_path, synthetic):
@@ -362,7 +416,7 @@ def test_header_compiles_as_c_and_cxx(tmp_path):
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert out.returncode == 0, out.stderr.decode()[-2000:]
     n, ver = out.stdout.decode().split()
-    assert int(n) == len(syms) and int(ver) == 3
+    assert int(n) == len(syms) and int(ver) == 4
 
 
 def test_reference_jitter_segment_plan():

@@ -289,6 +289,60 @@ def test_mt19937_jump_polynomials():
     assert np.array_equal(got[1:], want[1:]) and ((int(got[0]) ^ int(want[0])) & 0x80000000) == 0
 
 
+def test_randperm_prefix_is_torch_randperm(oracle):
+    """The oracle's statement of ``torch.randperm(n)[:B]`` (RayGenerator.select, reference utils/dataload.py:150-153) against
+    torch itself: forward Fisher-Yates over the generator's raw 32-bit outputs, n - 1 draws per call -- ids bit-exact from
+    arbitrary stream positions, full permutations and prefixes, tiny n (every step collides) to 2e5; and a generator
+    patched with the counters utils/host_rng.py predicts for n - 1 draws continues exactly like one that shuffled."""
+    from nerf_simple_amd.utils import host_rng as H
+    for n in (1, 2, 3, 7, 50, 623, 624, 625, 1000, 8192, 200_003):
+        for B in (1, 5, 64, 4096):
+            g = torch.Generator()
+            g.manual_seed(n * 31 + B)
+            torch.rand(n % 700, generator=g)
+            st = g.get_state()
+            left, _, nxt, words = H._parse(st)
+            want = torch.randperm(n, generator=g)[:B].numpy()
+            first = min(B, max(n - 1, 0))
+            draws, _ = oracle.mt19937_uniform(words.astype(np.uint32), 625 - left, first, raw=True)
+            assert np.array_equal(oracle.randperm_prefix(n, B, draws), want), (n, B)
+            # bookkeeping: all n - 1 draws of the call, regenerated blocks included
+            _, mt = oracle.mt19937_uniform(words.astype(np.uint32), 625 - left, max(n - 1, 0), raw=True)
+            new_left, new_next, blocks = H._advance(left, nxt, max(n - 1, 0))
+            g2 = torch.Generator()
+            g2.set_state(H._patched(st, new_left, new_next, mt if blocks else None))
+            assert torch.equal(g2.get_state(), g.get_state()), (n, B)
+
+
+def test_select_reproduces_the_reference_ray_ids(golden, oracle, synthetic):
+    """The reference's own call site: G6c and G8 store the ``ray_ids`` of reference runs (``rg.select`` as
+    ``torch.randperm(n)[:B]`` after ``torch.manual_seed``); the oracle's select gives them from the seeded generator's
+    state words, with the rays and target colours of train.py:47-49."""
+    from nerf_simple_amd.utils import host_rng as H
+    rays_tab, gt_tab = dataset_tables(golden, oracle, synthetic)
+    for g, key, B, seed in ((golden("train_cfg.npz"), "ray_ids", None, None), (golden("trajectory.npz"), "ray_ids0", None, 0)):
+        B = int(g["B"])
+        seed = int(g["seed"]) if "seed" in g.files else int(g["seeds"][0])
+        gen = torch.Generator()
+        gen.manual_seed(seed)
+        left, _, nxt, words = H._parse(gen.get_state())
+        rays, gt, ids = oracle.select(rays_tab, gt_tab, B, words.astype(np.uint32), 625 - left)
+        assert np.array_equal(ids.numpy(), g[key])
+        assert torch.equal(rays, rays_tab[t(g[key])]) and torch.equal(gt, gt_tab[t(g[key])])
+
+
+def test_counter_select_is_a_permutation_prefix(oracle):
+    """The counter-RNG selection (no reference counterpart): distinct ids in range for every (n, B), a full permutation at
+    B = n, another batch for another seed offset."""
+    for n, B in ((1, 1), (5, 5), (100, 100), (1000, 64), (16_000_000, 4096)):
+        ids = oracle.select_ids_counter(n, B, seed=3, seed_offset=1)
+        assert len(ids) == B and len(set(ids.tolist())) == B and ids.min() >= 0 and ids.max() < n
+        if B == n:
+            assert sorted(ids.tolist()) == list(range(n))
+    a, b = oracle.select_ids_counter(10 ** 6, 256, 3, 1), oracle.select_ids_counter(10 ** 6, 256, 3, 2)
+    assert len(set(a.tolist()) & set(b.tolist())) < 8
+
+
 def g9_module(g, i):
     """The module of fixture G9's i-th size, rebuilt as the reference built it: same seed of the CPU generator, same
     constructor order (our Nerf creates its nn.Linear layers in the reference's order, so nn.Linear's default
