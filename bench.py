@@ -26,11 +26,14 @@ Rank 0 prints ONE JSON line with the contract fields plus
   cpu_baseline  the CPU oracle (a PyTorch-CPU port of the reference) timed on this box's host
                 cores on a bounded sample (N=1 only), and the PSNR criterion of BASELINE.json on
                 the weights that were timed;
+  by_dtype      (render mode) the headline step for BOTH 16-bit operand types with the same number of timed
+                steps: value, kernel_ms, frac, psnr_delta_vs_teacher_db, meets_0.05_db -- fp16 (the default)
+                and bf16 (the type BASELINE config 3 names) side by side;
   aux           (render mode, N=1) a few seconds each of the other BASELINE.json configurations,
-                measured AFTER the timed region of the headline: the same render with bf16 operands
-                (the type north_star names; its PSNR delta is reported beside the fp16 default's),
-                config 2 (400x400x64, exact-fp32 MFMA), config 4 (800x800 hierarchical 64+128 in one
-                library call) and config 5 (the training step as replayed hipGraphs, N = 64 and 128);
+                measured AFTER the timed region of the headline: config 2 (400x400x64, exact-fp32 MFMA), config 4 (800x800 hierarchical 64+128 in one
+                library call), config 5 (the whole training iteration -- batch selection from a 16 M-ray table
+                included -- as replayed hipGraphs, N = 64 and 128) and shard8 (this GPU as rank 0 of 8: the 80,000-ray
+                shard render + its RCCL all-gather, and the training step + its all-reduce, on the wall clock);
   N > 1         per-rank kernel ms, the collective's ms (events around it on the launch stream), and
                 self-checks that fail loudly: backend is nccl (= RCCL), one distinct device per rank,
                 the rank-sum all-reduce.
@@ -328,6 +331,156 @@ def event_timed(fn, steps, warmup, dev):
     return e0.elapsed_time(e1) / steps
 
 
+def render_leg(dev, sd, rays, precision, steps, warmup):
+    """The headline step -- one launch of the fused render over ``rays`` -- for one operand type, timed exactly like the
+    headline (W warm-up launches, then K launches between two device synchronisations on the wall clock, and HIP events
+    around every launch on its stream).  Returns the by_dtype entry (PSNR fields are added by the cpu_baseline leg)."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.nets import Nerf, packed_status
+    lib = _lib.lib()
+    net = Nerf(precision=precision).to(dev)
+    net.load_state_dict(sd)
+    code = _lib.precision_code(precision)
+    packed = net.packed_weights(code)
+    n = rays.shape[0]
+    tb = torch.linspace(2, 6, N_SAMPLES + 1).to(dev)
+    px = torch.empty((n, 4), dtype=torch.float32, device=dev)
+
+    def one():
+        _lib.check(lib.nerf_amd_render_pixels_forward(_lib.ptr(rays), None, _lib.ptr(tb), _lib.ptr(packed), code, _lib.FLAG_DEVICE_RNG,
+                                                      1234, 0, _lib.ptr(px), None, n, N_SAMPLES, _lib.stream_ptr(dev)), "render leg")
+
+    for _ in range(warmup):
+        one()
+    torch.cuda.synchronize(dev)
+    evs = []
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        one()
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if packed_status(packed, code):
+        raise SystemExit(f"the {precision} render left the operand range")
+    kern_ms = sum(a.elapsed_time(b) for a, b in evs) / steps
+    samples = n * N_SAMPLES
+    peak = PEAK_F32 if precision == "fp32" else PEAK_BF16
+    traffic, src = pmc_traffic(RENDER_KERNEL[precision], "render", precision)
+    return {"value": samples * steps / elapsed, "unit": "ray-samples/s", "ms_per_step": elapsed / steps * 1e3, "steps": steps,
+            "warmup": warmup, "kernel": RENDER_KERNEL[precision], "kernel_ms": kern_ms,
+            "tflops": samples * FLOP_PER_SAMPLE / (kern_ms * 1e-3) / 1e12,
+            "frac": samples * FLOP_PER_SAMPLE / (kern_ms * 1e-3) / peak, "traffic": traffic, "traffic_source": src}
+
+
+def shard8_bound(dev, sd, rays_800, precision, full_step_ms):
+    """What one GPU can say about the 8-GPU step, END TO END (review item: the per-rank host cost around an 8.1 ms kernel
+    decides >= 6x, and no 8-GPU node was available to measure the curve).  This process renders exactly what rank 0 of 8
+    renders -- 80,000 rays of the 800 x 800 view, ray ids from 0, then the step's all_gather_into_tensor over RCCL (a group
+    of ONE rank, the collective issued all the same) -- and times >= 200 such steps on the WALL CLOCK, with HIP events on
+    the stream splitting the step into kernel and collective.  Same for the training step with its all-reduce."""
+    import torch.distributed as dist
+    from nerf_simple_amd import _lib, parallel
+    from nerf_simple_amd.optim import FusedAdam
+    from nerf_simple_amd.training import GraphedTrainStep
+    from nerf_simple_amd.utils import synthetic
+    from nerf_simple_amd.utils.nets import Nerf
+    global _JSON_OUT
+    if _JSON_OUT is None:                        # RCCL's banner goes to stdout: keep fd 1 for the one JSON line
+        sys.stdout.flush()
+        _JSON_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    own_group = not dist.is_initialized()
+    if own_group:
+        s_ = socket.socket()
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+        s_.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+        dist.init_process_group("nccl", device_id=dev)
+    parallel.force_collectives(True)
+    try:
+        lib = _lib.lib()
+        code = _lib.precision_code(precision)
+        net = Nerf(precision=precision).to(dev)
+        net.load_state_dict(sd)
+        packed = net.packed_weights(code)
+        n_full = rays_800.shape[0]
+        lo, hi = parallel.shard_range(n_full, 0, 8)
+        rays = rays_800[lo:hi].contiguous()
+        nr = hi - lo
+        tb = torch.linspace(2, 6, N_SAMPLES + 1).to(dev)
+        shard = torch.empty((nr, 4), dtype=torch.float32, device=dev)
+        image = torch.empty((n_full, 4), dtype=torch.float32, device=dev)
+        steps, warm = 400, 20
+        evs = []
+
+        def step(record):
+            if record:
+                ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                ev[0].record()
+            _lib.check(lib.nerf_amd_render_pixels_forward(_lib.ptr(rays), None, _lib.ptr(tb), _lib.ptr(packed), code,
+                                                          _lib.FLAG_DEVICE_RNG, 1234, lo, _lib.ptr(shard), None, nr, N_SAMPLES,
+                                                          _lib.stream_ptr(dev)), "shard render")
+            if record:
+                ev[1].record()
+            dist.all_gather_into_tensor(image[lo:hi], shard)      # one rank: its own slice of the image; 8 ranks: the image
+            if record:
+                ev[2].record()
+                evs.append(ev)
+
+        for _ in range(warm):
+            step(False)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        torch.cuda.synchronize(dev)
+        step_ms = (time.perf_counter() - t0) / steps * 1e3
+        kern = sum(e[0].elapsed_time(e[1]) for e in evs) / steps
+        coll = sum(e[1].elapsed_time(e[2]) for e in evs) / steps
+        out = {"workload": "rank 0 of 8: 80,000 rays x 128 samples of the 800x800 view + all_gather_into_tensor over RCCL "
+                           "(process group of one rank, collective issued all the same), wall clock over 400 steps",
+               "step_ms": step_ms, "kernel_ms": kern, "collective_ms": coll, "host_gap_ms": step_ms - kern - coll,
+               "full_image_step_ms": full_step_ms, "speedup_bound_8": full_step_ms / step_ms,
+               "note": "speedup_bound_8 = one-GPU full-image step / this step: what 8 GPUs reach if the wire time of a 1.28 MB "
+                       "per-rank all-gather stays inside the measured collective floor; the wire itself needs the 8-GPU node"}
+        # the training step of config 5 with its gradient all-reduce issued (2.38 MB, one rank)
+        rg = synthetic_ray_table(dev)
+        res = {}
+        for name, group in (("no_exchange", None), ("all_reduce", dist.group.WORLD)):
+            parallel.force_collectives(group is not None)
+            tnet = Nerf(precision="bf16").to(dev)
+            tnet.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+            st_ = GraphedTrainStep(tnet, FusedAdam(tnet, lr=5e-4), TRAIN_RAYS, TRAIN_SAMPLES, device_rng=True, seed=7, rays_from=rg,
+                                   group=group, timing=group is not None)
+            for _ in range(50):
+                st_.step()
+            st_.reset_timing()
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(2000):
+                st_.step()
+            torch.cuda.synchronize(dev)
+            res[name] = (time.perf_counter() - t0) / 2000 * 1e3
+            if group is not None:
+                ct = st_.collective_times()
+                res["collective_ms"] = ct[0] if ct else None
+            del st_, tnet
+        out["train"] = {"workload": "config 5 step (4096 x 64, batch selected from the 16 M-ray table in the graph) with and "
+                                    "without the flat-gradient all-reduce over RCCL (one rank), wall clock over 2000 steps",
+                        "step_ms_no_exchange": res["no_exchange"], "step_ms_all_reduce": res["all_reduce"],
+                        "collective_ms": res.get("collective_ms"),
+                        "weak_scaling_bound_8": res["no_exchange"] / res["all_reduce"]}
+        return out
+    finally:
+        parallel.force_collectives(False)
+        if own_group:
+            dist.destroy_process_group()
+
+
 TABLE_IMAGES = 25                      # 25 images of 800 x 800 = 16 M rays: the reference's lego table (num_train_imgs, configs/lego.yaml)
 
 
@@ -367,21 +520,8 @@ def aux_configs(dev, sd, rays_800):
         n.load_state_dict(synthetic.synthetic_state_dict(seed, kind))
         return n
 
-    # ---- config 3 with bf16 operands: the same launch, the other 16-bit type
     n_rays = rays_800.shape[0]
-    packed = net_of("bf16").packed_weights(_lib.BF16)
-    tb = torch.linspace(2, 6, N_SAMPLES + 1).to(dev)
     px = torch.empty((n_rays, 4), dtype=torch.float32, device=dev)
-    ms = event_timed(lambda: _lib.check(lib.nerf_amd_render_pixels_forward(
-        _lib.ptr(rays_800), None, _lib.ptr(tb), _lib.ptr(packed), _lib.BF16, _lib.FLAG_DEVICE_RNG, 1234, 0, _lib.ptr(px), None,
-        n_rays, N_SAMPLES, st()), "render bf16"), 20, 3, dev)
-    samples = n_rays * N_SAMPLES
-    tf_ = samples * FLOP_PER_SAMPLE / (ms * 1e-3)
-    traffic, src = pmc_traffic(RENDER_KERNEL["bf16"], "render", "bf16")
-    aux["bf16"] = {"workload": "config 3 (800x800x128) with bf16 MFMA operands, the type BASELINE config 3 names", "ms": ms,
-                   "ray_samples_per_s": samples / (ms * 1e-3), "kernel": RENDER_KERNEL["bf16"], "tflops": tf_ / 1e12,
-                   "frac_of_peak": tf_ / PEAK_BF16, "peak_tflops": PEAK_BF16 / 1e12, "steps": 20, "traffic": traffic,
-                   "traffic_source": src}
 
     # ---- config 2: 400x400, 64 samples per ray, exact-fp32 MFMA
     pose = torch.from_numpy(spherical_to_pose(4, -30, 0)).float()
@@ -535,8 +675,22 @@ def run_render(args):
                          "kernel_ms": kern_ms, "flop_per_sample": FLOP_PER_SAMPLE,
                          "samples_per_launch": launch_samples},
         }
+        res["by_dtype"] = {res["dtype"]: {"value": value, "unit": "ray-samples/s", "ms_per_step": elapsed / args.steps * 1e3,
+                                          "steps": args.steps, "warmup": args.warmup, "kernel": kern, "kernel_ms": kern_ms,
+                                          "tflops": achieved, "frac": achieved * 1e12 / peak, "traffic": traffic,
+                                          "traffic_source": traffic_src, "headline": True}}
         if not multi and not args.no_aux:
+            # the other 16-bit operand type with the SAME number of timed steps: both types carry equal statistical weight
+            # (fp16 is the default because it meets the 0.05 dB criterion on every weight set tried; bf16 is the type
+            # BASELINE config 3 names -- DESIGN.md section 2)
+            other = {"fp16": "bf16", "bf16": "fp16"}.get(args.precision)
+            if other:
+                res["by_dtype"][{"bf16": "bf16", "fp16": "f16"}[other]] = render_leg(dev, sd, rays, other, args.steps, args.warmup)
             res["aux"] = aux_configs(dev, sd, rays)
+            try:
+                res["aux"]["shard8"] = shard8_bound(dev, sd, rays, args.precision, elapsed / args.steps * 1e3)
+            except Exception as e:                       # a rehearsal: never take the headline line down with it
+                res["aux"]["shard8"] = {"error": f"{type(e).__name__}: {e}"}
         if not multi and not args.no_cpu_baseline:
             base, (crays, cu, cout, O) = cpu_baseline(sd, rays_cpu, args.cpu_rays)
             with torch.no_grad():
@@ -552,16 +706,19 @@ def run_render(args):
             base["max_abs_rgb_err"] = float((g[0].cpu() - cout[0]).abs().max())
             base["gpu_over_cpu"] = value / base["value"]
             res["cpu_baseline"] = base
-            if "aux" in res and args.precision != "bf16":
+            for key, prec in (("f16", "fp16"), ("bf16", "bf16"), ("f32", "fp32")):
+                if key not in res["by_dtype"]:
+                    continue
                 with torch.no_grad():
-                    gb = render_nerf(crays.to(dev), net, N_SAMPLES, u=cu.to(dev), precision="bf16")
-                bf_rgb = torch.clip(gb[0].cpu(), 0, 1)
-                d = float(O.img_psnr(T, bf_rgb)) - base["psnr_cpu_vs_teacher_db"]
-                res["aux"]["bf16"].update({"psnr_gpu_vs_cpu_db": float(O.img_psnr(cpu_rgb, bf_rgb)), "psnr_delta_vs_teacher_db": d,
-                                           "meets_0.05_db": abs(d) <= 0.05,
-                                           "note": "bf16's 8-bit weight mantissa shifts the image systematically on these "
-                                                   "high-gain weights (DESIGN.md section 2): the 0.05 dB criterion is a known "
-                                                   "gap of the bf16 operand mode, which is why fp16 operands are the default"})
+                    gb = g if prec == args.precision else render_nerf(crays.to(dev), net, N_SAMPLES, u=cu.to(dev), precision=prec)
+                p_rgb = torch.clip(gb[0].cpu(), 0, 1)
+                d = float(O.img_psnr(T, p_rgb)) - base["psnr_cpu_vs_teacher_db"]
+                res["by_dtype"][key].update({"psnr_gpu_vs_cpu_db": float(O.img_psnr(cpu_rgb, p_rgb)), "psnr_delta_vs_teacher_db": d,
+                                             "meets_0.05_db": abs(d) <= 0.05})
+            if "bf16" in res["by_dtype"] and not res["by_dtype"]["bf16"].get("meets_0.05_db", True):
+                res["by_dtype"]["bf16"]["note"] = ("bf16's 8-bit weight mantissa shifts the image systematically on these high-gain "
+                                                   "weights (DESIGN.md section 2): the 0.05 dB criterion is a known gap of the bf16 "
+                                                   "operand mode on them, which is why fp16 operands are the default")
         emit(res)
     if multi:
         dist.destroy_process_group()

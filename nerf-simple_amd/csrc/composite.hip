@@ -111,25 +111,25 @@ __global__ __launch_bounds__(64 * RAYS_PER_BLOCK) void composite_backward_kernel
             if (valid) {
                 const float t = rts[i];
                 const f32x4 c = rraw[i];
-                float delta = (i == N - 1) ? 1e10f : __fsub_rn(rts[i + 1], t);
-                delta = __fmul_rn(delta, dnorm);
+                float delta = (i == N - 1) ? 1e10f : sub_rn(rts[i + 1], t);
+                delta = mul_rn(delta, dnorm);
                 const float sigma = c[3];
                 const float sp = sigma > 20.f ? sigma : log1pf(expf(sigma));
                 const float spd = sigma > 20.f ? 1.0f : 1.0f / (1.0f + expf(-sigma));
-                a = __fsub_rn(1.0f, expf(__fmul_rn(-sp, delta)));
-                fac = __fadd_rn(__fsub_rn(1.0f, a), 1e-10f);
+                a = sub_rn(1.0f, expf(mul_rn(-sp, delta)));
+                fac = add_rn(sub_rn(1.0f, a), 1e-10f);
                 ds[ch] = (1.0f - a) * delta * spd;       // d alpha / d sigma
                 tt[ch] = t; cc[ch] = c;
             }
             // the forward compositor's scan (composite_device.h): same tree, same rounded products
             const float incl = nerf_composite::wave_scan_mul(fac);
             const float excl = nerf_composite::dpp_move<0x138, 0xf>(1.0f, incl);          // wave_shr:1
-            al[ch] = a; fc[ch] = fac; Tt[ch] = __fmul_rn(carry, excl);
-            carry = __fmul_rn(carry, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63)));
+            al[ch] = a; fc[ch] = fac; Tt[ch] = mul_rn(carry, excl);
+            carry = mul_rn(carry, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63)));
             if (valid) {
                 depth += a * Tt[ch] * tt[ch]; accw += a * Tt[ch];
                 // the same ops as the forward compositor (composite_device.h), so rgb_out equals its rgb
-                const float wt = __fmul_rn(a, Tt[ch]);
+                const float wt = mul_rn(a, Tt[ch]);
                 sr = __fmaf_rn(wt, cc[ch][0], sr); sg = __fmaf_rn(wt, cc[ch][1], sg); sb = __fmaf_rn(wt, cc[ch][2], sb);
             }
         }

@@ -11,7 +11,7 @@ namespace nerf_composite {
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off));
+    for (int off = 32; off >= 1; off >>= 1) v = add_rn(v, __shfl_xor(v, off));
     return v;
 }
 
@@ -24,22 +24,22 @@ __device__ __forceinline__ float dpp_move(float idle, float v) {
 }
 // inclusive product scan over the 64 lanes; every product is one rounded multiply
 __device__ __forceinline__ float wave_scan_mul(float x) {
-    x = __fmul_rn(x, dpp_move<0x111, 0xf>(1.0f, x));      // row_shr:1
-    x = __fmul_rn(x, dpp_move<0x112, 0xf>(1.0f, x));      // row_shr:2
-    x = __fmul_rn(x, dpp_move<0x114, 0xf>(1.0f, x));      // row_shr:4
-    x = __fmul_rn(x, dpp_move<0x118, 0xf>(1.0f, x));      // row_shr:8
-    x = __fmul_rn(x, dpp_move<0x142, 0xa>(1.0f, x));      // row_bcast:15 -> rows 1, 3
-    x = __fmul_rn(x, dpp_move<0x143, 0xc>(1.0f, x));      // row_bcast:31 -> rows 2, 3
+    x = mul_rn(x, dpp_move<0x111, 0xf>(1.0f, x));      // row_shr:1
+    x = mul_rn(x, dpp_move<0x112, 0xf>(1.0f, x));      // row_shr:2
+    x = mul_rn(x, dpp_move<0x114, 0xf>(1.0f, x));      // row_shr:4
+    x = mul_rn(x, dpp_move<0x118, 0xf>(1.0f, x));      // row_shr:8
+    x = mul_rn(x, dpp_move<0x142, 0xa>(1.0f, x));      // row_bcast:15 -> rows 1, 3
+    x = mul_rn(x, dpp_move<0x143, 0xc>(1.0f, x));      // row_bcast:31 -> rows 2, 3
     return x;
 }
 // sum over the 64 lanes as a wave-uniform value (the same tree with adds; lane 63 holds the total)
 __device__ __forceinline__ float wave_total(float x) {
-    x = __fadd_rn(x, dpp_move<0x111, 0xf>(0.f, x));
-    x = __fadd_rn(x, dpp_move<0x112, 0xf>(0.f, x));
-    x = __fadd_rn(x, dpp_move<0x114, 0xf>(0.f, x));
-    x = __fadd_rn(x, dpp_move<0x118, 0xf>(0.f, x));
-    x = __fadd_rn(x, dpp_move<0x142, 0xa>(0.f, x));
-    x = __fadd_rn(x, dpp_move<0x143, 0xc>(0.f, x));
+    x = add_rn(x, dpp_move<0x111, 0xf>(0.f, x));
+    x = add_rn(x, dpp_move<0x112, 0xf>(0.f, x));
+    x = add_rn(x, dpp_move<0x114, 0xf>(0.f, x));
+    x = add_rn(x, dpp_move<0x118, 0xf>(0.f, x));
+    x = add_rn(x, dpp_move<0x142, 0xa>(0.f, x));
+    x = add_rn(x, dpp_move<0x143, 0xc>(0.f, x));
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 
@@ -80,19 +80,19 @@ __device__ __forceinline__ void composite_ray(const Src& src, int N, int lane, f
         if (valid) {
             t = src.t(i);
             c = src.c(i);
-            float delta = (i == N - 1) ? 1e10f : __fsub_rn(src.t(i + 1), t);
-            delta = __fmul_rn(delta, dnorm);
+            float delta = (i == N - 1) ? 1e10f : sub_rn(src.t(i + 1), t);
+            delta = mul_rn(delta, dnorm);
             const float sigma = c[3];
             const float sp = sigma > 20.f ? sigma : log1pf(expf(sigma));      // softplus(beta=1, threshold=20)
-            a = __fsub_rn(1.0f, expf(__fmul_rn(-sp, delta)));
-            fac = __fadd_rn(__fsub_rn(1.0f, a), 1e-10f);
+            a = sub_rn(1.0f, expf(mul_rn(-sp, delta)));
+            fac = add_rn(sub_rn(1.0f, a), 1e-10f);
         }
         // inclusive product scan across the wave, shifted by one lane = exclusive cumprod (rendering.py:68)
         const float incl = wave_scan_mul(fac);
         const float excl = dpp_move<0x138, 0xf>(1.0f, incl);          // wave_shr:1
-        const float T = __fmul_rn(carry, excl);
-        const float wt = __fmul_rn(a, T);
-        carry = __fmul_rn(carry, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63)));
+        const float T = mul_rn(carry, excl);
+        const float wt = mul_rn(a, T);
+        carry = mul_rn(carry, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(incl), 63)));
         if (valid) {
             // per-sample outputs are streamed (8 B per sample when requested): non-temporal stores
             if (o.alpha) __builtin_nontemporal_store(a, o.alpha + ray * N + i);
@@ -101,7 +101,7 @@ __device__ __forceinline__ void composite_ray(const Src& src, int N, int lane, f
             sg = __fmaf_rn(wt, c[1], sg);
             sb = __fmaf_rn(wt, c[2], sb);
             sd = __fmaf_rn(wt, t, sd);
-            sa = __fadd_rn(sa, wt);
+            sa = add_rn(sa, wt);
         }
     }
     sr = wave_total(sr); sg = wave_total(sg); sb = wave_total(sb);

@@ -150,8 +150,30 @@ __device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigne
     return (float)(philox_word(seed, ctr) >> 8) * (1.0f / 16777216.0f);
 }
 
+// ---- one IEEE operation, one rounding -------------------------------------------------------------
+// hipcc compiles with -ffp-contract=fast-honor-pragmas and its __fmul_rn / __fadd_rn / __fsub_rn are plain `a * b`,
+// `a + b`: a product that feeds a sum becomes ONE v_fma / v_fmac whatever the spelling, and __fsqrt_rn is the bare
+// v_sqrt_f32 (1 ulp, not correctly rounded).  Where the reference's result has to be reproduced bit for bit -- sample
+// positions feed sin(2^9 x): one ulp of y is 1e-4 rad there, and a high-gain network turns that into 5e-5 of alpha --
+// the operations are these: the pragma keeps the `contract` flag off the instruction, so nothing fuses with it.
+// (Found by the error model of tests/error_model.py: the fp32 render sat 40x further from the float64 value than the
+// reference's own fp32 result, the fp32 MLP on given points did not.)
+__device__ __forceinline__ float mul_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a * b;
+}
+__device__ __forceinline__ float add_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float sub_rn(float a, float b) {
+#pragma clang fp contract(off)
+    return a - b;
+}
+__device__ __forceinline__ float sqrt_rn(float a) { return sqrtf(a); }       // correctly rounded (v_sqrt + one correction step)
+
 __device__ __forceinline__ float norm3(float x, float y, float z) {
-    return __fsqrt_rn(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+    return sqrt_rn(__fmaf_rn(z, z, __fmaf_rn(y, y, mul_rn(x, x))));
 }
 
 // One query point: position (un-normalised direction times t) and the unit
@@ -161,7 +183,7 @@ struct PointIn {
 };
 
 // rays mode (reference utils/rendering.py:24-40).  Every product/sum is
-// rounded separately (__fmul_rn/__fadd_rn: no fma contraction) exactly like
+// rounded separately (mul_rn / add_rn above: no fma contraction) exactly like
 // the reference's separate torch ops, so ts and locs are bit-identical to the
 // CPU path given the same u.
 // (ray, sample) of point p = base + local, where (b0, r0) = divmod(base, N) is known (one wave-uniform
@@ -223,13 +245,13 @@ __device__ __forceinline__ PointIn fetch_point_rays(const MlpArgs& a, long long 
             u = have_u ? u_pre : philox_uniform(effective_seed(a), (unsigned long long)((a.ray_id0 + b) * a.N + i));
         else
             u = __builtin_nontemporal_load(a.u + p);
-        const float bin_diff = __fsub_rn(a.tbins[1], a.tbins[0]);
-        t = __fadd_rn(__fmul_rn(bin_diff, u), a.tbins[i]);
+        const float bin_diff = sub_rn(a.tbins[1], a.tbins[0]);
+        t = add_rn(mul_rn(bin_diff, u), a.tbins[i]);
     }
     r.t = t;
-    r.x = __fadd_rn(ox, __fmul_rn(dx, t));
-    r.y = __fadd_rn(oy, __fmul_rn(dy, t));
-    r.z = __fadd_rn(oz, __fmul_rn(dz, t));
+    r.x = add_rn(ox, mul_rn(dx, t));
+    r.y = add_rn(oy, mul_rn(dy, t));
+    r.z = add_rn(oz, mul_rn(dz, t));
     if constexpr (DIR) {
         // torch.norm over 3 elements on CPU == sqrt(fma(z,z,fma(y,y,x*x))) bit for bit
         const float nrm = norm3(dx, dy, dz);
@@ -263,7 +285,7 @@ __device__ __forceinline__ TwoF to_revolutions(float x) {
     const float C_HI = 0.15915494f;          // fl32(1/(2 pi))
     const float C_LO = 6.4206382e-09f;       // 1/(2 pi) - C_HI
     TwoF q;
-    q.hi = __fmul_rn(x, C_HI);
+    q.hi = mul_rn(x, C_HI);
     const float err = __fmaf_rn(x, C_HI, -q.hi);
     q.lo = __fmaf_rn(x, C_LO, err);
     return q;

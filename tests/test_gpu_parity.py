@@ -2,15 +2,15 @@
 mirror) against the golden vectors captured from the reference and against
 the CPU oracle on seeded inputs.
 
-Tolerances (stated once, used below; errors are max-abs / max(1, max|ref|)):
+Tolerances (errors are max-abs / max(1, max|ref|)); none is "k x what the GPU showed":
   ENC_ATOL   encoder vs torch-CPU: ocml sinf/cosf on the exactly scaled
              argument, ~1-2 ulp of a value in [-1,1].
-  TOL[(precision, weight set)]  the MLP and the whole render against the goldens, at <= 3x the
-             error observed on MI355X:
-               fp32  exact-f32 MFMA: same arithmetic, different summation order (k-permuted fma
-                     chain vs MKL sgemm blocking) through 12 layers: 1.5e-7 / 3.6e-5 observed
-               fp16  11-bit mantissa operands, fp32 accumulate: 6e-5 / 2.4e-3 observed
-               bf16  8-bit mantissa operands: 7e-4 / 1.6e-2 observed
+  TOL[(precision, weight set)] and the per-output bounds of test_mlp_golden / test_render_golden come from
+             tests/error_model.py: an independent CPU model of the stated numerics on the same inputs --
+               fp16 / bf16  the oracle with every layer's operands rounded to the MFMA operand type, fp32
+                            accumulate; the GPU's error per output <= 1.5 x the emulated error (+ the fp32 bound);
+               fp32         the kernel against the FLOAT64 value of the same expression: its error per output
+                            <= 2 x the error of the reference's own fp32 result;
              ("default" = nn.Linear-scale weights, "structured" = He-scale hidden weights with x8
              head gains); the image-level criterion is PSNR (test_image_psnr).
   CMP_RTOL   compositor alone: identical formulas, scan order differs from
@@ -23,10 +23,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 ENC_ATOL = 5e-7
-TOL = {("fp32", "default"): 5e-7, ("fp32", "structured"): 1e-4,
-       ("fp16", "default"): 2e-4, ("fp16", "structured"): 7e-3,
-       ("bf16", "default"): 2e-3, ("bf16", "structured"): 4.5e-2}
-F32_TOL = TOL[("fp32", "structured")]
+import error_model                                       # noqa: E402  (tests/error_model.py)
+from error_model import TOL                              # noqa: E402  derived on first use, on the CPU
+F32S = ("fp32", "structured")
+
+
+def f32_tol():
+    """The fp32 kernel against an fp32 result of the reference (golden / fp32 oracle) on the structured weights."""
+    return error_model.vs_fp32_result(F32S)
 CMP_RTOL = 2e-5
 CMP_ATOL = 1e-6
 NAMES = ("rgb", "disp", "alpha", "acc", "w")
@@ -93,16 +97,18 @@ def test_encode_empty_and_other_levels(dev, oracle):
 @pytest.mark.parametrize("kind", ["default", "structured"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_mlp_golden(dev, golden, synthetic, kind, precision):
-    tol = TOL[(precision, kind)]
+    """G2 through Nerf.forward; per output the bound of tests/error_model.py (16-bit: 1.5 x the emulated operand-rounding
+    error against the golden; fp32: 2 x the reference's own fp32 error against the float64 value)."""
     g = golden(f"mlp_{kind}.npz")
     net = make_net(synthetic, dev, kind, precision)
     with torch.no_grad():
         out = net.forward(t(g["v"]).to(dev))
     assert out.shape == (512, 4)
-    err_rgb = scaled_err(out.cpu().numpy()[:, :3], g["out"][:, :3])
-    err_sig = scaled_err(out.cpu().numpy()[:, 3], g["out"][:, 3])
-    print(f"mlp {kind} {precision}: rgb {err_rgb:.3e} sigma {err_sig:.3e}")
-    assert err_rgb <= tol and err_sig <= tol
+    bound, truth = error_model.mlp_model(kind, precision)
+    err_rgb = scaled_err(out.cpu().numpy()[:, :3], truth[:, :3])
+    err_sig = scaled_err(out.cpu().numpy()[:, 3], truth[:, 3])
+    print(f"mlp {kind} {precision}: rgb {err_rgb:.3e} (bound {bound['rgb']:.3e}) sigma {err_sig:.3e} (bound {bound['sigma']:.3e})")
+    assert err_rgb <= bound["rgb"] and err_sig <= bound["sigma"]
 
 
 @pytest.mark.parametrize("P", [1, 31, 257, 1000])
@@ -191,7 +197,7 @@ def test_mlp_repack_after_update(dev, oracle, synthetic):
     with torch.no_grad():
         c = net.forward(v.to(dev)).cpu()
         want = oracle.nerf_forward(sd2, v)
-    assert scaled_err(c.numpy(), want.numpy()) <= F32_TOL
+    assert scaled_err(c.numpy(), want.numpy()) <= f32_tol()
 
 
 # ---------------------------------------------------------------- compositing
@@ -244,7 +250,8 @@ def test_composite_odd_sizes(dev, oracle):
 @pytest.mark.parametrize("kind", ["default", "structured"])
 @pytest.mark.parametrize("precision", ["fp32", "bf16", "fp16"])
 def test_render_golden(dev, golden, synthetic, kind, precision):
-    tol = TOL[(precision, kind)]
+    """G4 through render_nerf, all five outputs at N = 32 ... 192, each against its own modelled bound
+    (tests/error_model.py render_model)."""
     from nerf_simple_amd.utils.rendering import render_nerf, render_rays
     assert render_rays is render_nerf
     g = golden(f"render_{kind}.npz")
@@ -253,11 +260,10 @@ def test_render_golden(dev, golden, synthetic, kind, precision):
     for N in (32, 64, 128, 192):
         with torch.no_grad():
             outs = render_nerf(rays, net, N, u=t(g[f"N{N}_u"]).to(dev))
-        errs = {}
-        for n, o in zip(NAMES, outs):
-            errs[n] = scaled_err(o.cpu().numpy(), g[f"N{N}_{n}"])
-        print(f"render {kind} {precision} N={N}: " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()))
-        assert max(errs.values()) <= tol, errs
+        bound, truth = error_model.render_model(kind, precision, N)
+        errs = {n: scaled_err(o.cpu().numpy(), truth[n]) for n, o in zip(NAMES, outs)}
+        print(f"render {kind} {precision} N={N}: " + " ".join(f"{k}={v:.2e}/{bound[k]:.2e}" for k, v in errs.items()))
+        assert all(errs[n] <= bound[n] for n in NAMES), (errs, bound)
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16", "fp32"])
@@ -392,7 +398,7 @@ def test_render_rng_consumption(dev, golden, synthetic):
     torch.manual_seed(int(g["N64_seed"]))
     torch.rand(256, 64)
     assert torch.equal(after, torch.rand(1))
-    assert scaled_err(a[0].cpu().numpy(), g["N64_rgb"]) <= F32_TOL
+    assert scaled_err(a[0].cpu().numpy(), g["N64_rgb"]) <= f32_tol()
 
 
 def test_render_ts_given_and_sample_positions(dev, golden, synthetic, oracle):
@@ -426,7 +432,7 @@ def test_render_generic_net(dev, golden, synthetic):
     with torch.no_grad():
         a = render_nerf(t(g["rays"]).to(dev), Wrapped(), 64, u=u)
     for n, o in zip(NAMES, a):
-        assert scaled_err(o.cpu().numpy(), g[f"N64_{n}"]) <= F32_TOL, n
+        assert scaled_err(o.cpu().numpy(), g[f"N64_{n}"]) <= f32_tol(), n
 
 
 def test_device_rng(dev, synthetic):
@@ -473,32 +479,36 @@ def test_image_golden_fp32(dev, golden, synthetic, kind):
     pose = t(g["pose"])
     rgbs, disps = render_poses(net, [pose], [100, 100, f], batch_size=int(g["batch_size"]), N=32, u=u)
     rgb, disp = rgbs[0].reshape(-1, 3), disps[0].reshape(-1)
-    assert scaled_err(rgb, g["rgb"]) <= F32_TOL and scaled_err(disp, g["disp"]) <= F32_TOL
+    assert scaled_err(rgb, g["rgb"]) <= f32_tol() and scaled_err(disp, g["disp"]) <= f32_tol()
     assert rgb.min() >= 0.0 and rgb.max() <= 1.0
     # a non-divisor batch size renders the tail too and changes nothing
     rgbs2, disps2 = render_poses(net, [pose], [100, 100, f], batch_size=3333, N=32, u=u)
     assert np.array_equal(rgbs2[0], rgbs[0]) and np.array_equal(disps2[0], disps[0])
 
 
-# (kind, precision) -> (max |PSNR(GPU,T) - PSNR(CPU,T)| dB, min PSNR(GPU,CPU) dB)
-# BASELINE's criterion is 0.05 dB.  fp32 and fp16 (the default render precision) meet it on both weight
-# sets.  bf16 meets it at nn.Linear weight scale ("default": 0.044 dB observed) and measures 0.21 dB
-# on the "structured" stress set; its bound there is the observed value + 20 %, NOT the criterion.
+# BASELINE's criterion: |PSNR(GPU,T) - PSNR(CPU,T)| <= 0.05 dB, for EVERY precision and weight set.  fp32 and fp16 (the
+# default render precision) meet it on both weight sets, bf16 at nn.Linear weight scale ("default"); bf16 on the
+# "structured" stress set does NOT (0.21 dB measured) -- a known gap of that operand mode, marked as an expected failure
+# so that the criterion stays the criterion (strict: if bf16 ever meets it the mark must go).
 # Why bf16 cannot meet it (tests/studies/precision_study.py): the error that
 # moves PSNR is the rounding of the WEIGHTS (a systematic perturbation of the network, correlated by
 # chance with any other low-dimensional perturbation such as the teacher's), every layer contributes
 # +-0.05..0.1 dB with either sign, and no subset of layers in fp16 short of all of them keeps three
 # test views inside 0.05 dB.  fp16 operands cost 5.0 % of throughput (clock) against bf16.
-PSNR_BOUNDS = {("default", "bf16"): (0.05, 66.0), ("structured", "bf16"): (0.25, 46.0),
-               ("default", "fp16"): (0.05, 84.0), ("structured", "fp16"): (0.05, 63.0),
-               ("default", "fp32"): (0.01, 130.0), ("structured", "fp32"): (0.01, 100.0)}
+PSNR_CRITERION_DB = 0.05
+PSNR_CASES = [pytest.param(k, p, marks=pytest.mark.xfail(strict=True, reason="bf16 operands miss the 0.05 dB criterion on the "
+                                                                        "high-gain weight set (weight rounding): known gap"))
+              if (k, p) == ("structured", "bf16") else (k, p)
+              for k in ("default", "structured") for p in ("bf16", "fp16", "fp32")]
 
 
-@pytest.mark.parametrize("kind,precision", sorted(PSNR_BOUNDS))
+@pytest.mark.parametrize("kind,precision", PSNR_CASES)
 def test_image_psnr(dev, golden, synthetic, oracle, kind, precision):
-    """|PSNR(GPU,T) - PSNR(CPU,T)| against a synthetic target T = CPU render of a
-    perturbed 'teacher' (SURVEY.md section 8d), reference PSNR formula
-    (train.py:21-26, peak = max(gt)); plus PSNR(GPU, CPU) itself."""
+    """|PSNR(GPU,T) - PSNR(CPU,T)| <= 0.05 dB against a synthetic target T = CPU render of a
+    perturbed 'teacher' (SURVEY.md section 8d), reference PSNR formula (train.py:21-26, peak = max(gt)); plus
+    PSNR(GPU, CPU) itself against what the modelled numerics reach (tests/error_model.py image_model): the GPU image may
+    carry at most 1 dB more error power than the CPU emulation of its operand type (16-bit), and for fp32 is compared
+    with the float64 image: at most 3 dB (2 x the power) more than the reference's own fp32 image carries."""
     from nerf_simple_amd.utils.rendering import render_poses
     g = golden(f"image_{kind}.npz")
     u_cpu = t(golden("image_u.npz")["u"])
@@ -511,12 +521,12 @@ def test_image_psnr(dev, golden, synthetic, oracle, kind, precision):
     rays = oracle.camera_rays(t(g["pose"]), [100, 100, f])
     T, _ = oracle.render_image(teacher, rays, 2500, N=32, u=u_cpu)
     p_gpu, p_cpu = float(oracle.img_psnr(T, gpu)), float(oracle.img_psnr(T, cpu))
-    p_gc = float(oracle.img_psnr(cpu, gpu))
+    p_model, against = error_model.image_model(kind, precision)
+    p_gc = float(oracle.img_psnr(against, gpu.to(against.dtype)))
     print(f"{kind} {precision}: PSNR(CPU,T)={p_cpu:.3f} dB PSNR(GPU,T)={p_gpu:.3f} dB "
-          f"PSNR(GPU,CPU)={p_gc:.2f} dB")
-    dmax, pmin = PSNR_BOUNDS[(kind, precision)]
-    assert abs(p_gpu - p_cpu) <= dmax
-    assert p_gc >= pmin
+          f"PSNR(GPU, {'float64 image' if precision == 'fp32' else 'CPU'})={p_gc:.2f} dB (modelled numerics: {p_model:.2f} dB)")
+    assert p_gc >= p_model - (3.0 if precision == "fp32" else 1.0)
+    assert abs(p_gpu - p_cpu) <= PSNR_CRITERION_DB
 
 
 def test_image_psnr_three_views_fp16(dev, golden, synthetic, oracle):
@@ -576,9 +586,9 @@ def test_precision_override(dev, golden, synthetic):
         b = render_nerf(rays, net, 64, u=u)
         v = t(golden("mlp_structured.npz")["v"]).to(dev)
         o32 = net.forward(v, precision="fp32")
-    assert scaled_err(a[0].cpu().numpy(), g["N64_rgb"]) <= F32_TOL
-    assert F32_TOL < scaled_err(b[0].cpu().numpy(), g["N64_rgb"]) <= TOL[("bf16", "structured")]
-    assert scaled_err(o32.cpu().numpy(), golden("mlp_structured.npz")["out"]) <= F32_TOL
+    assert scaled_err(a[0].cpu().numpy(), g["N64_rgb"]) <= f32_tol()
+    assert f32_tol() < scaled_err(b[0].cpu().numpy(), g["N64_rgb"]) <= TOL[("bf16", "structured")]
+    assert scaled_err(o32.cpu().numpy(), golden("mlp_structured.npz")["out"]) <= f32_tol()
 
 
 def test_generate_rays_golden(dev, golden):
@@ -609,8 +619,8 @@ def test_render_view_golden(dev, golden, synthetic, kind):
         a = render_view(net, g["pose"], cam, N=32, u=u[:3333], ray0=0, n_rays=3333)
         b = render_view(net, g["pose"], cam, N=32, u=u[3333:], ray0=3333)
     assert px.shape == (10000, 4)
-    assert scaled_err(px[:, :3].cpu().numpy(), g["rgb"]) <= F32_TOL
-    assert scaled_err(px[:, 3].cpu().numpy(), g["disp"]) <= F32_TOL
+    assert scaled_err(px[:, :3].cpu().numpy(), g["rgb"]) <= f32_tol()
+    assert scaled_err(px[:, 3].cpu().numpy(), g["disp"]) <= f32_tol()
     assert torch.equal(torch.cat([a, b]), px)
     # device RNG: sharding-invariant
     with torch.no_grad():
@@ -665,7 +675,7 @@ def test_render_hierarchical(dev, oracle, synthetic, golden):
     # amplifies that where the pdf is nearly flat: compare in distribution
     dts = (ts_f.cpu() - wts).abs()
     assert float((dts <= 5e-4).float().mean()) >= 0.995 and float(dts.max()) <= 2e-2
-    assert scaled_err(coarse[0].cpu().numpy(), wc[0].numpy()) <= F32_TOL
+    assert scaled_err(coarse[0].cpu().numpy(), wc[0].numpy()) <= f32_tol()
     # the fine pass sees slightly different positions (sampler rounding): looser
     assert scaled_err(fine[0].cpu().numpy(), wf[0].numpy()) <= 5e-3
     assert scaled_err(fine[3].cpu().numpy(), wf[3].numpy()) <= 5e-3
@@ -695,8 +705,8 @@ def test_render_image_dropin(dev, golden, synthetic, oracle):
     rgb, disp, gt = render_image(net, FakeRG(), batch_size=4000, im_idx=1, im_set="val", N=32, u=u.to(dev))
     assert rgb.shape == (1, H, W, 3) and disp.shape == (1, H, W, 1) and gt.shape == (1, H, W, 3)
     assert not rgb.is_cuda and float(gt.min()) == 1.0
-    assert scaled_err(rgb.reshape(-1, 3).numpy(), g["rgb"]) <= F32_TOL
-    assert scaled_err(disp.reshape(-1).numpy(), g["disp"]) <= F32_TOL
+    assert scaled_err(rgb.reshape(-1, 3).numpy(), g["rgb"]) <= f32_tol()
+    assert scaled_err(disp.reshape(-1).numpy(), g["disp"]) <= f32_tol()
 
 
 def test_render_poses_several_poses(dev, synthetic, oracle):
@@ -963,3 +973,91 @@ def test_headline_workload_properties(dev, synthetic, oracle, precision):
     got = view[sub].cpu().numpy()
     worst = scaled_err(got[:, :3], want[0].clamp(0, 1).numpy())
     assert worst <= tol, worst
+
+
+def test_config2_workload_properties(dev, synthetic, oracle):
+    """BASELINE config 2 at its real size -- 400 x 400, 64 samples per ray, exact-fp32 MFMA, one launch -- with the
+    properties of test_headline_workload_properties: the one-launch view == the reference's batched loop (10 batches of
+    16,000 rays, utils/rendering.py:139-151) bit for bit over all 160,000 pixels; 48 scattered rays rendered ALONE
+    reproduce their pixels bit for bit; 24 of them through the CPU oracle, with the jitter the kernel drew, inside the
+    fp32 tolerance of the golden tests; rgb in [0, 1] after the clip."""
+    from nerf_simple_amd import _lib
+    from nerf_simple_amd.utils.rendering import generate_rays, render_nerf, render_view
+    from nerf_simple_amd.utils.xyz import spherical_to_pose
+    H = W = 400
+    N, SEED = 64, 12
+    net = make_net(synthetic, dev, "structured", "fp32")
+    pose = spherical_to_pose(4, -30, 0)
+    cam = [H, W, synthetic.focal_from_fov(W)]
+    with torch.no_grad():
+        view = render_view(net, pose, cam, N=N, device_rng=True, seed=SEED)
+        rays = generate_rays(pose, cam, dev)
+        parts = [render_nerf(rays[s:s + 16000], net, N, device_rng=True, seed=SEED, ray_id0=s, outputs=("rgb", "disp"))[:2]
+                 for s in range(0, H * W, 16000)]
+    assert len(parts) == 10 and view.shape == (H * W, 4)
+    rgb_b, disp_b = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    assert torch.equal(view[:, :3], rgb_b.clamp(0, 1))
+    assert torch.equal(torch.nan_to_num(view[:, 3], nan=-1.0), torch.nan_to_num(disp_b, nan=-1.0))
+    assert float(view[:, :3].min()) >= 0 and float(view[:, :3].max()) <= 1 and float(view[:, :3].std()) > 0.05
+    gen = torch.Generator().manual_seed(6)
+    picks = torch.cat([torch.tensor([0, W - 1, H * W - W, H * W - 1, 15999, 16000, 16001]),     # corners, a batch seam
+                       torch.randint(0, H * W, (41,), generator=gen)]).tolist()
+    for r in picks:
+        with torch.no_grad():
+            rgb, disp, _, _, _ = render_nerf(rays[r:r + 1].contiguous(), net, N, device_rng=True, seed=SEED, ray_id0=r)
+        assert torch.equal(rgb.clamp(0, 1)[0], view[r, :3]), r
+        assert torch.equal(torch.nan_to_num(disp, nan=-1.0)[0], torch.nan_to_num(view[r, 3:4], nan=-1.0)[0]), r
+    lib = _lib.lib()
+    tb = torch.linspace(2, 6, N + 1).to(dev)
+    sub = picks[:24]
+    sel = rays[sub].contiguous()
+    us = []
+    for i, r in enumerate(sub):
+        raw, ts = torch.empty(1, N, 4, device=dev), torch.empty(1, N, device=dev)
+        _lib.check(lib.nerf_amd_mlp_forward_rays(_lib.ptr(sel[i:i + 1]), None, _lib.ptr(tb), _lib.ptr(net.packed_weights()),
+                                                 _lib.F32, _lib.FLAG_DEVICE_RNG, SEED, r, _lib.ptr(raw), _lib.ptr(ts), 1, N,
+                                                 _lib.stream_ptr(dev)), "ts")
+        us.append(ts.cpu())
+    with torch.no_grad():
+        want = oracle.render_nerf(sel.cpu(), synthetic.synthetic_state_dict(0, "structured"), N, ts=torch.cat(us))
+    got = view[sub].cpu().numpy()
+    assert scaled_err(got[:, :3], want[0].clamp(0, 1).numpy()) <= f32_tol()
+    assert scaled_err(np.nan_to_num(got[:, 3], nan=-1.0), np.nan_to_num(want[1].numpy(), nan=-1.0)) <= f32_tol()
+
+
+def test_config4_workload_properties(dev, synthetic, oracle):
+    """BASELINE config 4 at its real size -- 800 x 800, 64 coarse + 128 fine samples, ONE library call per view
+    (nerf_amd_render_hierarchical_forward) -- against its own pieces (the sampler has no reference counterpart: parity
+    unpinned; both render passes are the pinned render_nerf):
+      * the whole view == the eight 80,000-ray shards of it that eight ranks would render (ray0 / n_rays), bit for bit;
+      * on 4,000 scattered rows of the image, the one call == the three-stage composition render_hierarchical
+        (coarse render_nerf -> sample_pdf -> fine render_nerf on explicit positions) with the same global ray ids;
+      * merged positions sorted and inside [tn, tf], rgb in [0, 1], disparity finite wherever anything was hit."""
+    from nerf_simple_amd.utils.nets import Nerf
+    from nerf_simple_amd.utils.rendering import generate_rays, render_hierarchical, render_hierarchical_view
+    from nerf_simple_amd.utils.xyz import spherical_to_pose
+    H = W = 800
+    Nc, Nf, SEED = 64, 128, 3
+    nc, nf = make_net(synthetic, dev, "structured", "fp16"), Nerf(precision="fp16").to(dev)
+    nf.load_state_dict(synthetic.synthetic_state_dict(7, "structured"))
+    pose = spherical_to_pose(4, -30, 0)
+    cam = [H, W, synthetic.focal_from_fov(W)]
+    with torch.no_grad():
+        view = render_hierarchical_view(nc, nf, pose, cam, Nc, Nf, device_rng=True, seed=SEED)
+        shards = [render_hierarchical_view(nc, nf, pose, cam, Nc, Nf, device_rng=True, seed=SEED, ray0=r * 80000, n_rays=80000)
+                  for r in range(8)]
+    assert view.shape == (H * W, 4)
+    assert torch.equal(torch.nan_to_num(torch.cat(shards), nan=-1.0), torch.nan_to_num(view, nan=-1.0))
+    assert float(view[:, :3].min()) >= 0 and float(view[:, :3].max()) <= 1 and float(view[:, :3].std()) > 0.05
+    assert torch.isfinite(view[:, :3]).all()
+    rays = generate_rays(pose, cam, dev)
+    for r0 in (0, 3 * W + 17, 399 * W + 400, H * W - 1000):                       # four runs of 1,000 consecutive pixels
+        with torch.no_grad():
+            fine, coarse, ts_f = render_hierarchical(rays[r0:r0 + 1000].contiguous(), nc, nf, Nc, Nf, device_rng=True, seed=SEED,
+                                                     ray_id0=r0)
+        assert torch.equal(view[r0:r0 + 1000, :3], fine[0].clamp(0, 1)), r0
+        assert torch.equal(torch.nan_to_num(view[r0:r0 + 1000, 3], nan=-1.0), torch.nan_to_num(fine[1], nan=-1.0)), r0
+        assert ts_f.shape == (1000, Nc + Nf) and bool((ts_f[:, 1:] >= ts_f[:, :-1]).all())
+        assert float(ts_f.min()) >= 2.0 and float(ts_f.max()) <= 6.0
+        hit = fine[3] > 1e-3
+        assert torch.isfinite(fine[1][hit]).all()

@@ -43,6 +43,23 @@ def kernels(asm):
             yield d
 
 
+def lane_moves(asm, mangled):
+    """SGPR spills become v_writelane_b32 / v_readlane_b32 on the vector ALU: how many sit INSIDE the kernel's MFMA stream
+    (first to last v_mfma: the layer loop of a tile) and how many outside it (tile prologue, compositing, kernel prologue)."""
+    try:
+        a = asm.index(mangled + ":")
+        body = asm[a:asm.index(".Lfunc_end", a)].split("\n")
+    except ValueError:
+        return None
+    mf = [i for i, l in enumerate(body) if "v_mfma" in l]
+    if not mf:
+        return None
+    inside = lambda i: mf[0] < i < mf[-1]                    # noqa: E731
+    rd = [i for i, l in enumerate(body) if "v_readlane_b32" in l]
+    wr = [i for i, l in enumerate(body) if "v_writelane_b32" in l]
+    return len(mf), sum(map(inside, rd)), len(rd), sum(map(inside, wr)), len(wr)
+
+
 def main():
     srcs = [(a, []) for a in sys.argv[1:]] or DEFAULT
     for src, defs in srcs:
@@ -54,6 +71,10 @@ def main():
             nm = names.get(k[".name"], k[".name"]).replace("(anonymous namespace)::", "")
             print(f"  {nm}")
             print("     " + "  ".join(f"{f[1:]}={k.get(f, '?')}" for f in FIELDS))
+            lm = lane_moves(asm, k[".name"])
+            if lm and (lm[2] or lm[4]):
+                print(f"     lane moves (SGPR spill traffic): v_readlane {lm[2]} ({lm[1]} between the first and the last of the "
+                      f"{lm[0]} MFMAs), v_writelane {lm[4]} ({lm[3]} between them)")
         consts = re.findall(r"constexpr int (LDS_TOTAL(?:_COMP)?|LDS_BYTES)\b", open(os.path.join(CSRC, src)).read())
         if consts:
             print(f"     dynamic LDS is added at launch: see {', '.join(sorted(set(consts)))} in {src}")
