@@ -61,7 +61,7 @@ TRAIN_RAYS, TRAIN_SAMPLES = 4096, 64   # per GPU (reference configs/lego.yaml:12
 DW_BYTES_PER_POINT = 11_776            # operands nerf_amd_param_gradients reads once per point
 # committed rocprofv3 PMC summaries (tools/profile_gpu.sh + tools/summarize_prof.py), newest first
 PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in
-                 ("r03_bench_fp16_pmc.json", "r03_bench_bf16_pmc.json", "r03_train_pmc.json",
+                 ("r04_bench_fp16_pmc.json", "r04_train_pmc.json", "r03_bench_fp16_pmc.json", "r03_bench_bf16_pmc.json", "r03_train_pmc.json",
                   "r02_bench_pmc.json", "r02e_train_pmc.json")]
 
 

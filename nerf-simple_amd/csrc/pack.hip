@@ -88,41 +88,57 @@ __global__ void pack_bias_kernel(const float* __restrict__ params, float* __rest
 // the verdict (and leaves the scratch words zero for the next launch).  Weights repaired through the flat vector therefore
 // stop being flagged at the next re-pack.
 constexpr int PACK_SCRATCH_FLAG = 8, PACK_SCRATCH_COUNT = 9;       // words of the status block, zero between launches
-__global__ void pack_train_kernel(const float* __restrict__ params, __bf16* __restrict__ img, float* __restrict__ bias,
-                                  __bf16* __restrict__ bwd, unsigned* __restrict__ status) {
+// One workgroup per 1 KiB fragment (512 elements, two per thread): which image, layer, row tile and k-step a fragment is
+// follows from blockIdx alone -- scalar code, once per workgroup -- and a thread is left with a few bit operations and one
+// multiply-add per element.  (The element-per-thread form with the layer search, two divisions and the LayerDesc chains
+// evaluated per ELEMENT took 53-68 us, 5 % of a training step; this form: profiles/r04_train_rocprofv3_summary.txt.)
+constexpr int PACK_TRAIN_BIAS_WGS = (F32_BIAS_FLOATS + 511) / 512;
+constexpr int PACK_TRAIN_WGS = B16_WEIGHT_KIB + BWD_WEIGHT_KIB + PACK_TRAIN_BIAS_WGS;
+__global__ __launch_bounds__(256) void pack_train_kernel(const float* __restrict__ params, __bf16* __restrict__ img,
+                                                         float* __restrict__ bias, __bf16* __restrict__ bwd,
+                                                         unsigned* __restrict__ status) {
     if (blockIdx.x == 0 && threadIdx.x < B16_STATUS_BYTES / 4 && threadIdx.x != NERF_STATUS_WORD_WEIGHT_RANGE &&
         threadIdx.x != PACK_SCRATCH_FLAG && threadIdx.x != PACK_SCRATCH_COUNT)
         status[threadIdx.x] = 0u;
     bool bad = false;
-    const long long n_img = (long long)B16_WEIGHT_KIB * 512, n_bwd = (long long)BWD_WEIGHT_KIB * 512;
-    const long long total = n_img + n_bwd + F32_BIAS_FLOATS;
-    for (long long e = blockIdx.x * (long long)blockDim.x + threadIdx.x; e < total;
-         e += (long long)gridDim.x * blockDim.x) {
-        if (e < n_img) {
-            const int kib = (int)(e >> 9);
-            int L = 0;
-            while (L + 1 < NUM_LAYERS && kib >= b16_layer_off_kib(L + 1)) ++L;
-            const int rel = kib - b16_layer_off_kib(L);
-            const int rt = rel / b16_ks(L), s = rel % b16_ks(L);
-            const int lane = (int)(e >> 3) & 63, j = (int)e & 7;
-            const __bf16 cv = (__bf16)weight_at(params, L, 16 * rt + (lane & 15), src_col_b16(L, s, lane >> 4, j));
-            img[e] = cv;
-            bad |= !(__builtin_fabsf((float)cv) < __builtin_inff());                                          // as pack_b16_kernel
-        } else if (e < n_img + n_bwd) {
-            const long long q = e - n_img;
-            const int kib = (int)(q >> 9);
-            int b = 0;
-            while (b + 1 < NUM_BWD && kib >= bwd_layer_off_kib(b + 1)) ++b;
-            const int rel = kib - bwd_layer_off_kib(b);
-            const int rt = rel / bwd_ks(b), s = rel % bwd_ks(b);
-            const int lane = (int)(q >> 3) & 63, j = (int)q & 7;
-            const int o = bwd_src_out(b, s, lane >> 4, j);
-            bwd[q] = (__bf16)(o < 0 ? 0.f : weight_at(params, bwd_desc(b).wl, o, 16 * rt + (lane & 15)));
-        } else {
-            const int q = (int)(e - n_img - n_bwd);
-            int L = 0;
-            while (L + 1 < NUM_LAYERS && q >= f32_bias_off(L + 1)) ++L;
-            bias[q] = bias_at(params, L, q - f32_bias_off(L));
+    const int wg = blockIdx.x;
+    if (wg < B16_WEIGHT_KIB) {
+        const int kib = wg;
+        int L = 0;
+        while (L + 1 < NUM_LAYERS && kib >= b16_layer_off_kib(L + 1)) ++L;
+        const int rel = kib - b16_layer_off_kib(L);
+        const int rt = rel / b16_ks(L), s_ = rel % b16_ks(L);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = threadIdx.x + 256 * h;                 // element of the fragment: [lane][8]
+            const int lane = e >> 3, j = e & 7;
+            const __bf16 cv = (__bf16)weight_at(params, L, 16 * rt + (lane & 15), src_col_b16(L, s_, lane >> 4, j));
+            img[(long long)kib * 512 + e] = cv;
+            bad |= !(__builtin_fabsf((float)cv) < __builtin_inff());                                      // as pack_b16_kernel
+        }
+    } else if (wg < B16_WEIGHT_KIB + BWD_WEIGHT_KIB) {
+        const int kib = wg - B16_WEIGHT_KIB;
+        int b = 0;
+        while (b + 1 < NUM_BWD && kib >= bwd_layer_off_kib(b + 1)) ++b;
+        const int rel = kib - bwd_layer_off_kib(b);
+        const int rt = rel / bwd_ks(b), s_ = rel % bwd_ks(b);
+        const int wl = bwd_desc(b).wl;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int e = threadIdx.x + 256 * h;
+            const int lane = e >> 3, j = e & 7;
+            const int o = bwd_src_out(b, s_, lane >> 4, j);
+            bwd[(long long)kib * 512 + e] = (__bf16)(o < 0 ? 0.f : weight_at(params, wl, o, 16 * rt + (lane & 15)));
+        }
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = (wg - B16_WEIGHT_KIB - BWD_WEIGHT_KIB) * 512 + threadIdx.x + 256 * h;
+            if (q < F32_BIAS_FLOATS) {
+                int L = 0;
+                while (L + 1 < NUM_LAYERS && q >= f32_bias_off(L + 1)) ++L;
+                bias[q] = bias_at(params, L, q - f32_bias_off(L));
+            }
         }
     }
     if (__syncthreads_or(bad) && threadIdx.x == 0) atomicOr(&status[PACK_SCRATCH_FLAG], 1u);
@@ -141,7 +157,7 @@ __global__ void pack_train_kernel(const float* __restrict__ params, __bf16* __re
 extern "C" int nerf_amd_launch_pack_train(const float* params, void* packed_bf16, void* packed_bwd, hipStream_t stream) {
     (void)hipGetLastError();
     char* img = reinterpret_cast<char*>(packed_bf16);
-    hipLaunchKernelGGL(pack_train_kernel, dim3(2048), dim3(256), 0, stream, params, reinterpret_cast<__bf16*>(img),
+    hipLaunchKernelGGL(pack_train_kernel, dim3(PACK_TRAIN_WGS), dim3(256), 0, stream, params, reinterpret_cast<__bf16*>(img),
                        reinterpret_cast<float*>(img + (long long)B16_WEIGHT_KIB * 1024), reinterpret_cast<__bf16*>(packed_bwd),
                        reinterpret_cast<unsigned*>(img + B16_STATUS_OFF));
     return (int)hipGetLastError();

@@ -18,7 +18,7 @@
 //
 // (a position p > i is only ever written by a step whose partner it is, with the value that step displaced from its own
 // position; for j_i = i both lines say the same).  pred and dup are found by comparing against all earlier partners --
-// B^2 / 2 comparisons, spread over B / 64 workgroups: 8 us for the reference's batch of 4096 -- and the chains behind
+// B^2 / 2 comparisons, spread over B / 64 workgroups -- and the chains behind
 // a_i are followed in the gather kernel (their expected length is B / n).  Exact for every (n, B), collisions included:
 // oracle/nerf_oracle.py randperm_prefix is the sequential statement, pinned against torch.randperm itself.
 //
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_scan_kernel(const unsigned
                                                                   int* __restrict__ pred, int* __restrict__ dup) {
     __shared__ unsigned js[SEL_CHUNK];
     __shared__ int pred_s[SEL_ROWS], dup_s[SEL_ROWS];
-    const int t = threadIdx.x, row = t & (SEL_ROWS - 1), part = t / SEL_ROWS;
+    const int t = threadIdx.x, row = t & (SEL_ROWS - 1), lane = row, part = __builtin_amdgcn_readfirstlane(t / SEL_ROWS);
     const unsigned base = blockIdx.x * SEL_ROWS;
     const unsigned i = base + row;
     const unsigned hi = min(base + SEL_ROWS, B);                 // partners of rows < hi are all this workgroup looks at
@@ -67,20 +67,41 @@ __global__ __launch_bounds__(SEL_THREADS) void select_scan_kernel(const unsigned
     for (unsigned c0 = 0; c0 < hi; c0 += SEL_CHUNK) {
         const unsigned cn = min((unsigned)SEL_CHUNK, hi - c0);
         __syncthreads();                                         // the previous chunk has been read
-        for (unsigned k = t; k < cn; k += SEL_THREADS) js[k] = swap_partner(c0 + k, n, draws, seed);
-        __syncthreads();
-        // this wave's quarter of the chunk; every lane reads the same address (an LDS broadcast), four partners per read
-        const unsigned per = (cn + 15u) / 16u * 4u;              // a multiple of 4: the 16-byte reads stay aligned
-        const unsigned q0 = part * per, q1 = min(q0 + per, cn);
-        for (unsigned k = q0; k < q1; k += 4) {
-            const uint4 v = *reinterpret_cast<const uint4*>(js + k);
-            const unsigned jk[4] = {v.x, v.y, v.z, v.w};
+        // 16 partners per thread at most: eight independent Philox chains at a time (one chain is ~700 dependent cycles)
+        for (unsigned k0 = t; k0 < cn; k0 += 8 * SEL_THREADS) {
+            unsigned v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned kk = c0 + k + e;                  // ascending: the last match is the latest
-                if (kk < i && k + e < q1) {
-                    if (jk[e] == i) p = (int)kk;
-                    if (jk[e] == my_j) d = (int)kk;
+            for (int e = 0; e < 8; ++e) {
+                const unsigned k = k0 + e * SEL_THREADS;
+                v[e] = swap_partner(k < cn ? c0 + k : 0u, n, draws, seed);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (k0 + e * SEL_THREADS < cn) js[k0 + e * SEL_THREADS] = v[e];
+        }
+        __syncthreads();
+        // this wave's quarter of the chunk, 64 partners at a time: one LDS read per lane, then the 64 values go round the
+        // wave as scalars (v_readlane_b32), so the compare loop waits for no memory (a broadcast LDS read per partner made
+        // this loop latency-bound: 42 us for 4096 rows; this form: see profiles/r04_select_kernels.txt)
+        const unsigned per = (cn + 255u) / 256u * 64u;
+        const unsigned q0 = part * per, q1 = min(q0 + per, cn);
+        for (unsigned kb = q0; kb < q1; kb += 64) {
+            const unsigned mine = kb + lane < cn ? js[kb + lane] : 0xffffffffu;       // the pad matches no row and no partner
+            const unsigned kbase = c0 + kb;
+            if (kbase + 64u <= base) {                           // every partner of the block is earlier than every row
+#pragma unroll
+                for (int e = 0; e < 64; ++e) {
+                    const unsigned jk = __builtin_amdgcn_readlane(mine, e);
+                    if (jk == i) p = (int)(kbase + e);           // ascending: the last match is the latest
+                    if (jk == my_j) d = (int)(kbase + e);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 64; ++e) {
+                    const unsigned jk = __builtin_amdgcn_readlane(mine, e);
+                    const bool earlier = kbase + e < i;
+                    if (earlier && jk == i) p = (int)(kbase + e);
+                    if (earlier && jk == my_j) d = (int)(kbase + e);
                 }
             }
         }

@@ -1,4 +1,4 @@
-"""The bench contract, checked on the committed lines (profiles/r03_bench.json, profiles/r03_train_bench.json): every
+"""The bench contract, checked on the committed lines (profiles/r04_bench.json, profiles/r04_train_bench.json): every
 field the driver reads is there, the numbers are consistent with each other, and bench.py's own helpers (argument
 parsing, PMC lookup by full kernel instantiation) behave -- no GPU needed."""
 import importlib.util
@@ -31,7 +31,7 @@ def bench():
 
 
 def test_render_line():
-    d = load("r03_bench.json")
+    d = load("r04_bench.json")
     for k in REQUIRED + ("cpu_baseline", "aux"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["higher_is_better"] is True and d["vs_baseline"] is None
@@ -52,14 +52,30 @@ def test_render_line():
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and abs(c["psnr_delta_vs_teacher_db"]) <= 0.05
     aux = d["aux"]
-    assert set(aux) == {"bf16", "c2", "c4", "c5"} and set(aux["c5"]) == {"N64", "N128"}
-    for k in ("bf16", "c2", "c4"):
+    assert set(aux) == {"c2", "c4", "c5", "shard8"} and set(aux["c5"]) == {"N64", "N128"}
+    for k in ("c2", "c4"):
         assert aux[k]["ms"] > 0 and 0 < aux[k]["frac_of_peak"] < 1 and aux[k]["kernel"]
-    assert "psnr_delta_vs_teacher_db" in aux["bf16"] and aux["bf16"]["meets_0.05_db"] == (abs(aux["bf16"]["psnr_delta_vs_teacher_db"]) <= 0.05)
+    # both 16-bit operand types, timed alike, each with the PSNR criterion on the timed weights
+    by = d["by_dtype"]
+    assert set(by) == {"f16", "bf16"} and by[d["dtype"]].get("headline") is True
+    assert by[d["dtype"]]["value"] == d["value"] and by[d["dtype"]]["kernel_ms"] == d["roofline"]["kernel_ms"]
+    for k, v in by.items():
+        assert v["steps"] == d["steps"] and v["warmup"] == d["warmup"] and 0.4 < v["frac"] < 1 and v["kernel_ms"] <= v["ms_per_step"] * 1.001
+        assert v["meets_0.05_db"] == (abs(v["psnr_delta_vs_teacher_db"]) <= 0.05)
+    assert by["f16"]["meets_0.05_db"] is True
+    # the training iteration selects its batch from the 16 M-ray table inside the timed step
+    for n in ("N64", "N128"):
+        assert aux["c5"][n]["table_rays"] == 16_000_000 and "select_scan_kernel" in aux["c5"][n]["kernel"]
+    # rank 0 of 8 on the wall clock: kernel + collective + host gap = the step; eight such steps no slower than 1.33 full images
+    s8 = aux["shard8"]
+    assert "error" not in s8
+    assert abs(s8["step_ms"] - (s8["kernel_ms"] + s8["collective_ms"] + s8["host_gap_ms"])) < 1e-9
+    assert 8 * s8["step_ms"] <= 1.33 * s8["full_image_step_ms"] and s8["host_gap_ms"] < 0.1 * s8["step_ms"]
+    assert s8["train"]["step_ms_all_reduce"] >= s8["train"]["step_ms_no_exchange"] * 0.98
 
 
 def test_train_line():
-    d = load("r03_train_bench.json")
+    d = load("r04_train_bench.json")
     for k in REQUIRED:
         assert k in d, k
     assert d["scaling"] == "weak" and d["dtype"] == "bf16"
@@ -67,6 +83,7 @@ def test_train_line():
     assert abs(d["value"] - d["n_gpus"] * P / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["config"]["table_rays"] == 16_000_000 and "rg.select" in d["config"]["batch"]
 
 
 def test_pmc_lookup_needs_the_exact_instantiation(bench):

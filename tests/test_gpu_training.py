@@ -737,3 +737,33 @@ def test_diverged_eager_training_is_loud(dev, golden, synthetic):
         for _ in range(3):
             train_step(net, opt, rays, gt, N, u=u)
             torch.cuda.synchronize()
+
+
+def test_pack_train_decides_the_weight_range_word(dev, synthetic):
+    """nerf_amd_pack_weights_train states the weight-range word for exactly the weights it packs (the workgroups report
+    through two scratch words of the status block, the last one writes the verdict): a NaN weight sets it, weights
+    repaired through the flat vector clear it at the next re-pack -- it used to stay set until nerf_amd_pack_weights
+    (advisor finding, round 3) -- and the scratch words are zero again after every launch."""
+    from nerf_simple_amd import _lib
+    lib = _lib.lib()
+    st = _lib.stream_ptr(dev)
+    flat = synthetic.flatten_state_dict(synthetic.synthetic_state_dict(3, "default")).to(dev)
+    a = torch.zeros(int(lib.nerf_amd_packed_bytes(_lib.BF16)), dtype=torch.uint8, device=dev)
+    b = torch.zeros(int(lib.nerf_amd_packed_bytes(_lib.BF16_BWD)), dtype=torch.uint8, device=dev)
+    off = int(lib.nerf_amd_packed_status_offset(_lib.BF16))
+
+    def words():
+        torch.cuda.synchronize()
+        return a[off:off + 64].view(torch.int32).cpu().tolist()
+
+    _lib.check(lib.nerf_amd_pack_weights(_lib.ptr(flat), _lib.ptr(a), _lib.BF16, st), "p")
+    for bad_at in (None, 5, 300_000, None, 595_840, None):          # weights (fp32 biases are not operands: the forward's flag sees them)
+        w = flat.clone()
+        if bad_at is not None:
+            w[bad_at] = float("nan") if bad_at != 300_000 else float("inf")
+        a[off:off + 4].view(torch.int32)[0] = 7                              # word 0 (the forward's flag) is cleared by the re-pack
+        for _ in range(2):                                                   # twice: the scratch words start from zero each time
+            _lib.check(lib.nerf_amd_pack_weights_train(_lib.ptr(w), _lib.ptr(a), _lib.ptr(b), st), "pt")
+            got = words()
+            assert got[0] == 0 and got[1] == (0 if bad_at is None else 1), (bad_at, got)
+            assert got[8] == 0 and got[9] == 0, (bad_at, got)
