@@ -350,6 +350,17 @@ int nerf_amd_mt19937_uniform_par(const uint32_t* state624, int next, float* out,
                                  uint32_t* state_out624, const uint32_t* polys, int levels,
                                  int64_t seg_words, uint32_t* seg_states, void* stream);
 
+/* The reference's range warning, utils/xyz.py:8-9 (`input not in range -1,1, check rescaling`, raised by every gamma call
+ * of positional_encoder when any of the six query-point columns leaves [-1, 1]) without its two device->host syncs:
+ * *word |= 1 (uint32 in DEVICE memory, an atomic OR; the caller zeroes and reads it when it likes) if any query point of
+ * this call would trigger it.  rays != NULL: the points render_nerf would form from (rays[B,6], u, tbins, flags, seed,
+ * ray_id0, N) exactly as the render kernels form them; only the first and the last sample of each ray are looked at (a
+ * coordinate is monotone along its ray; with NERF_AMD_TS_GIVEN, whose positions need not be sorted, all N), so the cost is
+ * that of 2 B points.  pts != NULL (rays NULL): B FLOATS to test -- the 6 P values of explicit points [P,6], or any
+ * gamma() argument.  NaN coordinates do not warn (comparisons with NaN are false), as in the reference. */
+int nerf_amd_range_check(const float* rays, const float* pts, const float* u, const float* tbins, uint32_t flags,
+                         uint64_t seed, int64_t ray_id0, uint32_t* word, int64_t B, int N, void* stream);
+
 /* ---- ray selection: RayGenerator.select + the ground-truth gather, reference utils/dataload.py:141-153, train.py:47-49 ---- */
 /* The raw 32-bit outputs of the same generator (at::mt19937's random()): what `torch.randperm(n)` (dataload.py:151) draws
  * its swap positions from.  Arguments as nerf_amd_mt19937_uniform; state_out624 may be NULL. */

@@ -35,6 +35,7 @@ int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, 
 int nerf_amd_launch_mt19937_uniform(const uint32_t*, int, float*, long long, uint32_t*, hipStream_t);
 int nerf_amd_launch_mt19937_uniform_par(const uint32_t*, int, float*, long long, uint32_t*, const uint32_t*, int, long long,
                                         uint32_t*, hipStream_t);
+int nerf_amd_launch_range_check(const MlpArgs*, long long, unsigned*, hipStream_t);
 int nerf_amd_launch_mt19937_raw(const uint32_t*, int, uint32_t*, long long, uint32_t*, hipStream_t);
 int nerf_amd_launch_mt19937_advance(const uint32_t*, const uint32_t*, uint32_t*, hipStream_t);
 int nerf_amd_launch_select_rays(const uint32_t*, unsigned long long, const unsigned long long*, long long, long long, const float*,
@@ -198,6 +199,22 @@ int nerf_amd_query_points(const float* rays, const float* u, const float* tbins,
     a.rays = rays; a.u = u; a.tbins = tbins; a.ts_out = ts;
     a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
     return nerf_amd_launch_query_points(&a, query_pts, S(stream));
+}
+
+int nerf_amd_range_check(const float* rays, const float* pts, const float* u, const float* tbins, uint32_t flags, uint64_t seed,
+                         int64_t ray_id0, uint32_t* word, int64_t B, int N, void* stream) {
+    if (B < 0 || !word || (rays && pts)) return NERF_AMD_EINVAL;
+    if (B == 0) return 0;
+    MlpArgs a{};
+    if (pts) {
+        a.pts = pts; a.P = B;          // B floats
+    } else {
+        if (!rays || N <= 0) return NERF_AMD_EINVAL;
+        if (bad_jitter(flags, u, tbins)) return NERF_AMD_EINVAL;
+        a.rays = rays; a.u = u; a.tbins = tbins;
+        a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
+    }
+    return nerf_amd_launch_range_check(&a, B, word, S(stream));
 }
 
 int nerf_amd_mlp_forward(const float* pts, void* packed, float* out, int64_t P, int precision,

@@ -149,6 +149,35 @@ __global__ __launch_bounds__(256) void query_points_kernel(MlpArgs a, float* __r
     q[0] = pt.x; q[1] = pt.y; q[2] = pt.z; q[3] = pt.d1; q[4] = pt.d2; q[5] = pt.d3;
 }
 
+// The reference's range check (utils/xyz.py:8-9: `if torch.any(x < -1) or torch.any(x > 1): warnings.warn(...)` in every
+// gamma call of positional_encoder, i.e. on all six columns of the query points) without materialising the points and
+// without a host sync: *word |= 1 if any coordinate of any query point lies outside [-1, 1].
+//   rays mode (a.rays): one thread per RAY.  A coordinate o + d t is monotone in t -- also as the kernels round it: one
+//   rounded product, one rounded sum -- so its extremes over a ray's samples sit at the first and the last sample:
+//   two of the ray's N points decide for all of them, and those two are formed exactly as the render forms them
+//   (fetch_point_rays: explicit jitter, explicit positions or the counter RNG).  The unit direction is checked too.
+//   explicit positions (NERF_FLAG_TS_GIVEN) need not be sorted: every sample of the ray is looked at.
+//   flat mode (a.pts): B floats -- the six columns of given points, or any gamma() argument -- one thread per float.
+__global__ __launch_bounds__(256) void range_check_kernel(MlpArgs a, long long B, unsigned* __restrict__ word) {
+    const long long b = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    bool out = false;
+    if (a.pts) {
+        if (b < B) {
+            const float v = a.pts[b];
+            out = v < -1.f || v > 1.f;          // torch.any(x < -1) or torch.any(x > 1): NaN compares false and does not warn
+        }
+    } else if (b < B) {
+        const bool all = (a.flags & NERF_FLAG_TS_GIVEN) != 0;
+        const int step = all || a.N == 1 ? 1 : a.N - 1;
+        for (int i = 0; i < a.N; i += step) {
+            const PointIn pt = fetch_point_rays(a, b * a.N + i, RaySample{b, i});
+            out |= pt.x < -1.f || pt.x > 1.f || pt.y < -1.f || pt.y > 1.f || pt.z < -1.f || pt.z > 1.f || pt.d1 < -1.f ||
+                   pt.d1 > 1.f || pt.d2 < -1.f || pt.d2 > 1.f || pt.d3 < -1.f || pt.d3 > 1.f;
+        }
+    }
+    if (__any(out) && (threadIdx.x & 63) == 0) atomicOr(word, 1u);       // at most one atomic per wave
+}
+
 __host__ int grid_for(long long total) {
     long long g = (total + 255) / 256;
     return (int)(g < 1 ? 1 : (g > 256 * 32 ? 256 * 32 : g));
@@ -184,6 +213,14 @@ extern "C" int nerf_amd_launch_query_points(const MlpArgs* args, float* query_pt
     (void)hipGetLastError();
     if (args->P == 0) return 0;
     hipLaunchKernelGGL(query_points_kernel, dim3((unsigned)((args->P + 255) / 256)), dim3(256), 0, stream, *args, query_pts);
+    return (int)hipGetLastError();
+}
+
+extern "C" int nerf_amd_launch_range_check(const MlpArgs* args, long long B, unsigned* word, hipStream_t stream) {
+    (void)hipGetLastError();
+    const long long n = B;
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(range_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *args, B, word);
     return (int)hipGetLastError();
 }
 

@@ -685,6 +685,14 @@ class GraphedTrainStep:
         if self.check_every and self.opt.step_count % self.check_every == 0:
             # behind the forward, in front of graph B's re-pack (which clears the flag for the next step)
             self._watch.push(self._packed_fwd, self.opt.step_count)
+            # the reference's |x| > 1 warning (utils/xyz.py:8-9) on this step's batch, verdict raised lazily
+            from .utils.xyz import range_check_rays
+            if self.device_rng:
+                import ctypes
+                range_check_rays(self.rays, ctypes.c_void_p(self.hyper.data_ptr() + 24), self.tbins,
+                                 _lib.FLAG_DEVICE_RNG | _lib.FLAG_SEED_IN_MEMORY, self.seed, self.ray_id0, self.N)
+            else:
+                range_check_rays(self.rays, self.u, self.tbins, 0, 0, 0, self.N)
         if self.bucketed:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if self.timing else None
             if ev:

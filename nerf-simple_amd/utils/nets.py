@@ -265,6 +265,8 @@ class Nerf(nn.Module):
         _lib.require_cuda_f32(v, "v")
         if v.dim() != 2 or v.shape[1] != 6:
             raise RuntimeError("Nerf.forward expects a [P, 6] tensor")
+        from .xyz import range_check_values
+        range_check_values(v)                        # the reference's range warning (utils/xyz.py:8-9), raised lazily
         if not self._fused_ok():
             from . import generic_mlp
             if torch.is_grad_enabled():

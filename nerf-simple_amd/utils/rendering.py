@@ -115,6 +115,12 @@ def render_nerf(rays, net, N, tn=2, tf=6, *, u=None, ts=None, outputs=ALL_OUTPUT
         # the reference's single CPU draw per call (:28-30): same numbers, same advance of torch's
         # CPU generator, produced on the device (host_rng.py)
         jit, pending_rng = reference_rand(B, N, dev)
+    # the reference's |x| > 1 warning (utils/xyz.py:8-9, raised inside net.forward's positional_encoder): verdict formed on
+    # the device from the first / last sample of every ray, raised lazily (xyz.range_check_rays); a foreign net encodes
+    # its own inputs and warns (or not) by itself
+    if fused:
+        from .xyz import range_check_rays
+        range_check_rays(rays, jit, None if ts is not None else _tbins(tn, tf, N, dev), flags, seed, ray_id0, N)
     if pending_rng is not None and not fused:
         pending_rng.finish()                  # the net's own forward follows: the generator must be current
         pending_rng = None

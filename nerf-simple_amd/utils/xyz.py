@@ -6,14 +6,93 @@ host-side input generators, as in the reference.
 
 Differences from the reference, on purpose:
   * tensors must already be on the GPU (no CPU path);
-  * the "input not in range -1,1" UserWarning (utils/xyz.py:8-9) is not
-    raised: it is not part of the results, fires on every lego-scale point,
-    and costs two device->host syncs per call.
+  * the "input not in range -1,1, check rescaling" UserWarning (utils/xyz.py:8-9) is raised LAZILY: the reference
+    pays two device->host syncs per gamma call for it; here a kernel ORs the verdict into a device word
+    (nerf_amd_range_check), the word travels to pinned memory asynchronously, and the warning is issued by the next call
+    that finds the copy complete -- same text, same category, no host wait.  ``flush_range_warning()`` waits for it.
 """
+import warnings
+
 import numpy as np
 import torch
 
 from .. import _lib
+
+RANGE_WARNING = "input not in range -1,1, check rescaling"          # the reference's text (utils/xyz.py:9)
+
+
+class _RangeWatch:
+    """Per device: the word nerf_amd_range_check ORs into, its pinned host copy and the event behind that copy."""
+
+    def __init__(self, device):
+        self.word = torch.zeros(1, dtype=torch.int32, device=device)
+        self.host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.event = None
+
+    def poll(self, wait=False, stacklevel=4):
+        if self.event is None:
+            return
+        if wait:
+            self.event.synchronize()
+        if self.event.query():
+            self.event = None
+            if int(self.host[0]):
+                warnings.warn(RANGE_WARNING, UserWarning, stacklevel=stacklevel)
+
+    def after_launch(self):
+        """Behind a check kernel: if no copy is in flight, send the word home and clear it for the calls to come."""
+        if self.event is None and not torch.cuda.is_current_stream_capturing():
+            self.host.copy_(self.word, non_blocking=True)
+            self.word.zero_()
+            self.event = torch.cuda.Event()
+            self.event.record(torch.cuda.current_stream(self.word.device))
+
+
+_range_watch = {}
+
+
+def _watch(device):
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    if key not in _range_watch:
+        _range_watch[key] = _RangeWatch(torch.device("cuda", key))
+    return _range_watch[key]
+
+
+def range_check_values(x, stacklevel=4):
+    """The reference's check of one gamma() argument / of the query points [P,6] (all columns): enqueue, do not wait."""
+    if x.numel() == 0 or torch.cuda.is_current_stream_capturing():
+        return
+    w = _watch(x.device)
+    w.poll(stacklevel=stacklevel)
+    x = x.detach().contiguous()
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().nerf_amd_range_check(None, _lib.ptr(x), None, None, 0, 0, 0, _lib.ptr(w.word), x.numel(), 0,
+                                                   _lib.stream_ptr(x.device)), "nerf_amd_range_check")
+        w.after_launch()
+
+
+def range_check_rays(rays, jit, tbins, flags, seed, ray_id0, N, stacklevel=4):
+    """The same for the points render_nerf forms from its rays (first and last sample of every ray: a coordinate is
+    monotone along its ray): ``jit`` is a tensor, a ctypes pointer (seed-in-memory form) or None."""
+    if rays.shape[0] == 0:
+        return
+    w = _watch(rays.device)
+    w.poll(stacklevel=stacklevel)
+    jp = _lib.ptr(jit) if (jit is None or torch.is_tensor(jit)) else jit
+    with torch.cuda.device(rays.device):
+        _lib.check(_lib.lib().nerf_amd_range_check(_lib.ptr(rays), None, jp, _lib.ptr(tbins), int(flags), int(seed), int(ray_id0),
+                                                   _lib.ptr(w.word), rays.shape[0], int(N), _lib.stream_ptr(rays.device)),
+                   "nerf_amd_range_check")
+        w.after_launch()
+
+
+def flush_range_warning(device=None):
+    """Wait for the pending range verdicts (all devices, or one) and issue the warning now if one is due."""
+    for key, w in list(_range_watch.items()):
+        if device is None or torch.device(device).index in (None, key):
+            w.poll(wait=True, stacklevel=3)
 
 
 def gamma(x, L=4):
@@ -24,6 +103,7 @@ def gamma(x, L=4):
     if x.dim() != 2:
         raise RuntimeError("gamma expects a [P, C] tensor")
     P, C = x.shape
+    range_check_values(x, stacklevel=3)                 # utils/xyz.py:8-9, lazily
     lib = _lib.lib()
     cols = []
     with torch.cuda.device(x.device):
@@ -47,6 +127,7 @@ def positional_encoder(vec, Lp=10, Ld=4):
         raise RuntimeError("positional_encoder expects a [P, 6] tensor")
     vec = vec.contiguous()
     P = vec.shape[0]
+    range_check_values(vec, stacklevel=3)               # gamma's check on all six columns (utils/xyz.py:8-9, :26-31), lazily
     posx = torch.empty((P, 3 + 6 * Lp), dtype=torch.float32, device=vec.device)
     posd = torch.empty((P, 3 + 6 * Ld), dtype=torch.float32, device=vec.device)
     with torch.cuda.device(vec.device):
