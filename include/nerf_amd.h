@@ -381,7 +381,7 @@ int nerf_amd_mt19937_advance(const uint32_t* state624, const uint32_t* poly624, 
  *   draws == NULL: the counter RNG keyed by seed (+ *seed_mem if seed_mem != NULL: a uint64 in DEVICE memory read when the
  *                  kernel runs, so a launch captured into a hipGraph selects a fresh batch at every replay).
  * B <= n < 2^32 / 20 (beyond, torch.randperm is another algorithm: NERF_AMD_EUNSUP).  workspace: nerf_amd_select_workspace_bytes(B).
- * Two launches, no atomics on global memory, deterministic. */
+ * workspace 16-byte aligned.  Three launches, no atomics on global memory, deterministic. */
 int64_t nerf_amd_select_workspace_bytes(int64_t B);
 int nerf_amd_select_rays(const uint32_t* draws, uint64_t seed, const uint64_t* seed_mem, int64_t n, int64_t B,
                          const float* table, const float* colours, float* rays_out, float* gt_out, int64_t* ids_out,

@@ -584,7 +584,7 @@ int nerf_amd_mt19937_advance(const uint32_t* state624, const uint32_t* poly624, 
     return nerf_amd_launch_mt19937_advance(state624, poly624, state_out624, S(stream));
 }
 
-int64_t nerf_amd_select_workspace_bytes(int64_t B) { return B < 0 ? NERF_AMD_EINVAL : align_up(B * 12, 256); }
+int64_t nerf_amd_select_workspace_bytes(int64_t B) { return B < 0 ? NERF_AMD_EINVAL : align_up(B * 12 + 16, 256); }
 
 int nerf_amd_select_rays(const uint32_t* draws, uint64_t seed, const uint64_t* seed_mem, int64_t n, int64_t B,
                          const float* table, const float* colours, float* rays_out, float* gt_out, int64_t* ids_out,
@@ -593,7 +593,7 @@ int nerf_amd_select_rays(const uint32_t* draws, uint64_t seed, const uint64_t* s
     if (n >= (int64_t)(0xffffffffu / 20u)) return NERF_AMD_EUNSUP;      // torch.randperm switches algorithm there
     if (B == 0) return 0;
     if (!workspace || (rays_out && !table) || (gt_out && !colours)) return NERF_AMD_EINVAL;
-    if (((uintptr_t)table & 7) || ((uintptr_t)rays_out & 7) || ((uintptr_t)seed_mem & 7)) return NERF_AMD_EINVAL;
+    if (((uintptr_t)table & 7) || ((uintptr_t)rays_out & 7) || ((uintptr_t)seed_mem & 7) || ((uintptr_t)workspace & 15)) return NERF_AMD_EINVAL;
     return nerf_amd_launch_select_rays(draws, seed, reinterpret_cast<const unsigned long long*>(seed_mem), n, B, table, colours,
                                        rays_out, gt_out, reinterpret_cast<long long*>(ids_out), workspace, S(stream));
 }

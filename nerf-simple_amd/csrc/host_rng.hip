@@ -217,6 +217,8 @@ __global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict_
     if (third) atomicXor(dst + t + 512, a2);
 }
 
+__global__ void mt19937_zero_kernel(unsigned* __restrict__ words) { words[threadIdx.x] = 0u; }
+
 }  // namespace
 
 // Parallel form: the stream is cut into segments of seg_words words (a multiple of 624) after the
@@ -280,10 +282,11 @@ extern "C" int nerf_amd_launch_mt19937_raw(const uint32_t* state_in, int next, u
 extern "C" int nerf_amd_launch_mt19937_advance(const uint32_t* state_in, const uint32_t* poly, uint32_t* state_out,
                                                hipStream_t stream) {
     (void)hipGetLastError();
-    hipError_t e = hipMemsetAsync(state_out, 0, MT_N * sizeof(uint32_t), stream);
-    if (e != hipSuccess) return (int)e;
+    // a kernel, not hipMemsetAsync: captured into a hipGraph a memset NODE in front of atomics has been seen to leave the
+    // atomics on the buffer's old contents (csrc/dw_gemm.hip has the story); kernel -> kernel edges order correctly
+    hipLaunchKernelGGL(mt19937_zero_kernel, dim3(1), dim3(MT_N), 0, stream, state_out);
     const int lds = (MT_JUMP_BLOCKS + 2) * MT_N * (int)sizeof(unsigned);
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt19937_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt19937_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             MT_JUMP_LDS_MAX);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(mt19937_jump_kernel, dim3(MT_JUMP_SPLIT), dim3(256), lds, stream, state_out, poly, 0, 0, 0, 0, 1, state_in);

@@ -18,7 +18,7 @@
 //
 // (a position p > i is only ever written by a step whose partner it is, with the value that step displaced from its own
 // position; for j_i = i both lines say the same).  pred and dup are found by comparing against all earlier partners --
-// B^2 / 2 comparisons, spread over B / 64 workgroups -- and the chains behind
+// B^2 / 2 comparisons, spread over B / 16 workgroups -- and the chains behind
 // a_i are followed in the gather kernel (their expected length is B / n).  Exact for every (n, B), collisions included:
 // oracle/nerf_oracle.py randperm_prefix is the sequential statement, pinned against torch.randperm itself.
 //
@@ -34,8 +34,8 @@
 
 namespace {
 
-constexpr int SEL_ROWS = 64;            // rows i per workgroup: one wave's lanes
-constexpr int SEL_THREADS = 256;        // 4 waves: each scans a quarter of the earlier partners for the same 64 rows
+constexpr int SEL_ROWS = 16;            // rows i per workgroup: a lane is (row = lane & 15, partner stream = lane >> 4)
+constexpr int SEL_THREADS = 256;        // 4 waves x 4 lane groups = 16 partner streams over the same 16 rows
 constexpr int SEL_CHUNK = 4096;         // partners staged in LDS at a time (16 KiB)
 constexpr unsigned long long SEL_KEY = 0x73656c6563743a31ull;    // keeps the selection's Philox stream apart from the jitter's
 
@@ -46,19 +46,33 @@ __device__ __forceinline__ unsigned swap_partner(unsigned i, unsigned n, const u
     return i + z % (n - i);                                      // n < 2^32 / 20: no overflow
 }
 
-__global__ __launch_bounds__(SEL_THREADS) void select_scan_kernel(const unsigned* __restrict__ draws, unsigned long long seed,
-                                                                  const unsigned long long* __restrict__ seed_mem, unsigned n,
-                                                                  unsigned B, unsigned* __restrict__ partner,
+// partner[i] = j_i for the B rows, once (one thread per row)
+__global__ __launch_bounds__(256) void select_partner_kernel(const unsigned* __restrict__ draws, unsigned long long seed,
+                                                             const unsigned long long* __restrict__ seed_mem, unsigned n, unsigned B,
+                                                             unsigned* __restrict__ partner) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= B) return;
+    seed ^= SEL_KEY;
+    if (seed_mem) seed += *seed_mem;
+    partner[i] = swap_partner(i, n, draws, seed);
+}
+
+// pred(i), dup(i) for 16 rows per workgroup against all earlier partners.  Work per workgroup: hi partners loaded from L2
+// into LDS (16 bytes per thread and load) and hi x 16 comparisons pairs spread over 16 streams: every lane reads four
+// consecutive partners of ITS stream (ds_read_b128: four addresses per wave-instruction, one per lane group), so one
+// vector compare covers 16 rows x 4 partners.  (First form of this kernel: 64 rows per workgroup, every workgroup
+// recomputing all earlier partners, one scalar broadcast per partner -- 32-38 us inside a training step, 3 % of it: a
+// wave64 vector op is 4 cycles, and 1024 partners x 6 ops per wave is 25 k cycles.  This form: profiles/r04_select_kernels.txt.)
+__global__ __launch_bounds__(SEL_THREADS) void select_scan_kernel(unsigned B, const unsigned* __restrict__ partner,
                                                                   int* __restrict__ pred, int* __restrict__ dup) {
-    __shared__ unsigned js[SEL_CHUNK];
+    __shared__ __attribute__((aligned(16))) unsigned js[SEL_CHUNK];
     __shared__ int pred_s[SEL_ROWS], dup_s[SEL_ROWS];
-    const int t = threadIdx.x, row = t & (SEL_ROWS - 1), lane = row, part = __builtin_amdgcn_readfirstlane(t / SEL_ROWS);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int row = lane & 15, stream = wave * 4 + (lane >> 4);
     const unsigned base = blockIdx.x * SEL_ROWS;
     const unsigned i = base + row;
     const unsigned hi = min(base + SEL_ROWS, B);                 // partners of rows < hi are all this workgroup looks at
-    seed ^= SEL_KEY;
-    if (seed_mem) seed += *seed_mem;
-    const unsigned my_j = i < B ? swap_partner(i, n, draws, seed) : 0xffffffffu;
+    const unsigned my_j = i < B ? partner[i] : 0xffffffffu;
     if (t < SEL_ROWS) {
         pred_s[t] = -1;
         dup_s[t] = -1;
@@ -67,50 +81,35 @@ __global__ __launch_bounds__(SEL_THREADS) void select_scan_kernel(const unsigned
     for (unsigned c0 = 0; c0 < hi; c0 += SEL_CHUNK) {
         const unsigned cn = min((unsigned)SEL_CHUNK, hi - c0);
         __syncthreads();                                         // the previous chunk has been read
-        // 16 partners per thread at most: eight independent Philox chains at a time (one chain is ~700 dependent cycles)
-        for (unsigned k0 = t; k0 < cn; k0 += 8 * SEL_THREADS) {
-            unsigned v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const unsigned k = k0 + e * SEL_THREADS;
-                v[e] = swap_partner(k < cn ? c0 + k : 0u, n, draws, seed);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (k0 + e * SEL_THREADS < cn) js[k0 + e * SEL_THREADS] = v[e];
+        for (unsigned k = 4u * t; k < cn; k += 4u * SEL_THREADS) {           // the workspace is 16-byte aligned and padded
+            const uint4 v = *reinterpret_cast<const uint4*>(partner + c0 + k);
+            *reinterpret_cast<uint4*>(js + k) = v;
         }
         __syncthreads();
-        // this wave's quarter of the chunk, 64 partners at a time: one LDS read per lane, then the 64 values go round the
-        // wave as scalars (v_readlane_b32), so the compare loop waits for no memory (a broadcast LDS read per partner made
-        // this loop latency-bound: 42 us for 4096 rows; this form: see profiles/r04_select_kernels.txt)
-        const unsigned per = (cn + 255u) / 256u * 64u;
-        const unsigned q0 = part * per, q1 = min(q0 + per, cn);
-        for (unsigned kb = q0; kb < q1; kb += 64) {
-            const unsigned mine = kb + lane < cn ? js[kb + lane] : 0xffffffffu;       // the pad matches no row and no partner
-            const unsigned kbase = c0 + kb;
-            if (kbase + 64u <= base) {                           // every partner of the block is earlier than every row
+        // stream s takes the 16-byte blocks s, s + 16, s + 32, ...: ascending inside a lane, so its last match is its latest
+        for (unsigned k0 = 4u * stream; k0 < cn; k0 += 64u) {
+            const uint4 v = *reinterpret_cast<const uint4*>(js + k0);
+            const unsigned jk[4] = {v.x, v.y, v.z, v.w};
+            const unsigned kk = c0 + k0;
 #pragma unroll
-                for (int e = 0; e < 64; ++e) {
-                    const unsigned jk = __builtin_amdgcn_readlane(mine, e);
-                    if (jk == i) p = (int)(kbase + e);           // ascending: the last match is the latest
-                    if (jk == my_j) d = (int)(kbase + e);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 64; ++e) {
-                    const unsigned jk = __builtin_amdgcn_readlane(mine, e);
-                    const bool earlier = kbase + e < i;
-                    if (earlier && jk == i) p = (int)(kbase + e);
-                    if (earlier && jk == my_j) d = (int)(kbase + e);
-                }
+            for (int e = 0; e < 4; ++e) {
+                const bool live = kk + e < i && k0 + e < cn;     // an earlier row's partner (padding beyond cn is never live)
+                if (live && jk[e] == i) p = (int)(kk + e);
+                if (live && jk[e] == my_j) d = (int)(kk + e);
             }
         }
     }
-    if (p >= 0) atomicMax(&pred_s[row], p);
-    if (d >= 0) atomicMax(&dup_s[row], d);
+    // latest match over the 16 streams: the 4 lane groups of a wave by lane exchange, the 4 waves through LDS
+    p = max(p, __shfl_xor(p, 16));
+    p = max(p, __shfl_xor(p, 32));
+    d = max(d, __shfl_xor(d, 16));
+    d = max(d, __shfl_xor(d, 32));
+    if (lane < 16) {
+        if (p >= 0) atomicMax(&pred_s[row], p);
+        if (d >= 0) atomicMax(&dup_s[row], d);
+    }
     __syncthreads();
     if (t < SEL_ROWS && i < B) {
-        partner[i] = my_j;
         pred[i] = pred_s[t];
         dup[i] = dup_s[t];
     }
@@ -186,12 +185,15 @@ extern "C" int nerf_amd_launch_select_rays(const uint32_t* draws, unsigned long 
                                            long long n, long long B, const float* table, const float* colours, float* rays_out,
                                            float* gt_out, long long* ids_out, void* workspace, hipStream_t stream) {
     (void)hipGetLastError();
+    // workspace: partner[B rounded up to 4] | pred[B] | dup[B]  (nerf_amd_select_workspace_bytes)
+    const long long Bp = (B + 3) / 4 * 4;
     unsigned* partner = reinterpret_cast<unsigned*>(workspace);
-    int* pred = reinterpret_cast<int*>(partner + B);
+    int* pred = reinterpret_cast<int*>(partner + Bp);
     int* dup = pred + B;
+    hipLaunchKernelGGL(select_partner_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, draws, seed, seed_mem,
+                       (unsigned)n, (unsigned)B, partner);
     const unsigned rows = (unsigned)((B + SEL_ROWS - 1) / SEL_ROWS);
-    hipLaunchKernelGGL(select_scan_kernel, dim3(rows), dim3(SEL_THREADS), 0, stream, draws, seed, seed_mem, (unsigned)n, (unsigned)B,
-                       partner, pred, dup);
+    hipLaunchKernelGGL(select_scan_kernel, dim3(rows), dim3(SEL_THREADS), 0, stream, (unsigned)B, partner, pred, dup);
     hipLaunchKernelGGL(select_gather_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream, partner, pred, dup,
                        (unsigned)B, table, colours, rays_out, gt_out, ids_out);
     return (int)hipGetLastError();

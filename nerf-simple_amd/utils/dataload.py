@@ -92,6 +92,9 @@ class RayGenerator:
                    torch.empty((B, 3), dtype=torch.float32, device=dev) if cols is not None else None,
                    torch.empty((B,), dtype=torch.int64, device=dev))
         rays, gt, ids = out
+        for name, t_, shape, dt in (("rays", rays, (B, 6), torch.float32), ("gt", gt, (B, 3), torch.float32), ("ray_ids", ids, (B,), torch.int64)):
+            if t_ is not None and (tuple(t_.shape) != shape or t_.dtype != dt or t_.device != dev or not t_.is_contiguous()):
+                raise RuntimeError(f"select_batch: out {name} must be a contiguous {dt} tensor of shape {shape} on {dev}")
         if device_rng:
             self.launch(mode, B, None, int(seed), None, rays, gt, ids)
             return rays, gt, ids

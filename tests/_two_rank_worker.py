@@ -51,7 +51,9 @@ def main():
     # for the bucketed, overlapped form below
     tnet1 = Nerf(precision="bf16").to(dev)
     tnet1.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
-    step1 = GraphedTrainStep(tnet1, FusedAdam(tnet1, lr=5e-4), half, N, group=dist.group.WORLD, timing=True)
+    # group=None is the DEFAULT process group, as in train_step and everywhere in parallel.py: the replicas must exchange
+    # (round 3's `group is not None and ...` silently skipped the all-reduce here and let the replicas diverge)
+    step1 = GraphedTrainStep(tnet1, FusedAdam(tnet1, lr=5e-4), half, N, timing=True)
     assert step1.exchange and not step1.bucketed and step1.graph_a2 is None
     step1.step(rays[sl].to(dev), gt[sl].to(dev), u=uu[sl].to(dev))
     torch.cuda.synchronize()

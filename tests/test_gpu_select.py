@@ -260,3 +260,39 @@ def test_graphed_step_survives_a_checkpoint_restore(dev, synthetic, golden):
     l_fresh, l_rest = run(False), run(True)
     assert l_rest[0] == l_fresh[0], (l_rest, l_fresh)                     # the restored weights, bit for bit
     assert all(abs(a - b) <= 1e-4 * abs(b) for a, b in zip(l_rest, l_fresh)), (l_rest, l_fresh)
+
+
+def test_integration_select_stub_from_the_document(dev, oracle):
+    """INTEGRATION.md's third code block -- train.py:47-49 over the C ABI (counter-RNG form) -- run as printed, on top of
+    the first block (the library handle): B distinct rows, the oracle's ids for (seed, offset), rows gathered from both tables."""
+    import os
+    import re
+    import sys
+    import types
+    from nerf_simple_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    first = re.search(r"```python\n(# utils/_nerf_amd\.py.*?)```", text, flags=re.S).group(1)
+    third = re.search(r"```python\n(# utils/_nerf_amd_select\.py.*?)```", text, flags=re.S).group(1)
+    first = first.replace('ctypes.CDLL("libnerf_amd.so")', f'ctypes.CDLL("{_lib.LIB_PATH}")')
+    base = types.ModuleType("utils._nerf_amd")
+    exec(compile(first, "INTEGRATION.md:stub", "exec"), base.__dict__)
+    saved = {k: sys.modules.get(k) for k in ("utils", "utils._nerf_amd")}
+    sys.modules["utils"], sys.modules["utils._nerf_amd"] = types.ModuleType("utils"), base
+    try:
+        ns = {}
+        exec(compile(third, "INTEGRATION.md:select stub", "exec"), ns)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    n, B = 100_000, 512
+    table, colours = synthetic_tables(n, dev)
+    rays, gt, ids = ns["select"](table, colours, B, 5)
+    assert np.array_equal(ids.cpu().numpy(), oracle.select_ids_counter(n, B, 5))
+    assert torch.equal(rays, table[ids]) and torch.equal(gt, colours[ids]) and len(set(ids.tolist())) == B
+    word = torch.tensor([9], dtype=torch.int64, device=dev)
+    _, _, ids9 = ns["select"](table, colours, B, 5, step_word=word)
+    assert np.array_equal(ids9.cpu().numpy(), oracle.select_ids_counter(n, B, 5, 9))

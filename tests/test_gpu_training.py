@@ -766,4 +766,4 @@ def test_pack_train_decides_the_weight_range_word(dev, synthetic):
             _lib.check(lib.nerf_amd_pack_weights_train(_lib.ptr(w), _lib.ptr(a), _lib.ptr(b), st), "pt")
             got = words()
             assert got[0] == 0 and got[1] == (0 if bad_at is None else 1), (bad_at, got)
-            assert got[8] == 0 and got[9] == 0, (bad_at, got)
+            assert got[8] == 0 and got[9] == 0 and not any(got[16:24]), (bad_at, got)          # the protocol's scratch words

@@ -243,7 +243,7 @@ def test_abi_argument_errors(lib):
     assert lib.nerf_amd_select_rays(null, 0, null, 100, 16, one, one, one, one, one, null, null) == EINVAL     # no workspace
     assert lib.nerf_amd_select_rays(null, 0, null, 100, 16, ctypes.c_void_p(20), one, one, one, one, one, null) == EINVAL   # rows are read 8 bytes at a time
     assert lib.nerf_amd_select_rays(null, 0, null, 100, 16, null, one, one, one, one, one, null) == EINVAL     # rays out without a table
-    assert lib.nerf_amd_select_workspace_bytes(4096) == 49152
+    assert lib.nerf_amd_select_workspace_bytes(4096) == 49408
     assert lib.nerf_amd_mt19937_raw(null, 0, one, 4, null, null) == EINVAL
     assert lib.nerf_amd_mt19937_advance(one, one, one, null) == EINVAL                                          # in place
     assert lib.nerf_amd_mt19937_jump_poly(-1, one, one) == EINVAL
