@@ -566,14 +566,15 @@ def aux_configs(dev, sd, rays_800):
     for N, steps in ((64, 600), (128, 300)):
         net = net_of("bf16", 0, "default")
         # the whole iteration of train.py:47-57 inside the replayed graphs: rg.select + the colour gather from the 16 M-row
-        # tables (a fresh batch every step), fresh jitter, forward, backward, Adam, re-pack
+        # tables (a fresh batch every step, selected one step ahead beside the dX chain), fresh jitter, forward, backward,
+        # Adam, re-pack
         stepper = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), TRAIN_RAYS, N, device_rng=True, seed=7, rays_from=rg)
         ms = event_timed(stepper.step, steps, 30, dev)
         P = TRAIN_RAYS * N
         aux["c5"][f"N{N}"] = {"workload": f"config 5: train.py iteration, 4096 rays x {N} samples selected on the device from a "
                                           f"{n_table}-ray table every step, bf16, FusedAdam, hipGraph replay, 1 GPU",
                               "ms": ms, "ray_samples_per_s": P / (ms * 1e-3), "table_rays": n_table,
-                              "kernel": "select_scan_kernel + select_gather_kernel + nerf_mlp_bf16_16_kernel<true, true, false> + composite_backward_kernel + nerf_mlp_bwd_kernel + dw_gemm_kernel + adam_hyper_kernel + pack_train_kernel",
+                              "kernel": "select_partner_kernel + select_scan_kernel + select_gather_kernel + nerf_mlp_bf16_16_kernel<true, true, false> + composite_backward_kernel + nerf_mlp_bwd_kernel + dw_gemm_kernel + adam_hyper_kernel + pack_train_kernel",
                               "step_mfma_frac": 3 * FLOP_PER_SAMPLE * P / (ms * 1e-3) / PEAK_BF16, "peak_tflops": PEAK_BF16 / 1e12,
                               "final_loss": float(stepper.loss), "steps": steps}
         del stepper, net
@@ -800,7 +801,7 @@ def run_train(args):
                                    "(BASELINE config 5)",
                        "jitter": "fresh per step, device counter RNG inside the timed step",
                        "batch": f"fresh per step: rg.select + colour gather (train.py:47-49) from a {n_table}-ray table in HBM, "
-                                "inside the timed step (first two nodes of the replayed graph)",
+                                "inside the timed step (nodes of the replayed graph: each replay selects the next step's batch beside its dX chain)",
                        "table_rays": n_table,
                        "rays_per_gpu": B, "samples_per_ray": N, "global_batch_rays": B * world,
                        "parallelism": f"data-parallel x{world}" + (" + all_reduce of the flat 2.38 MB gradient" if multi else "")},

@@ -413,10 +413,12 @@ class GraphedTrainStep:
 
     ``rays_from`` = a ``utils.dataload.RayGenerator`` (tables resident in HBM): ``step()`` without rays then runs the
     first lines of the reference's iteration itself (train.py:47-49: ``rg.select(mode, N=batch_size)`` and the
-    ``train_imgs[ray_ids]`` gather) on the device -- with ``device_rng=True`` as the first node of graph A (counter RNG
-    keyed by seed + step, a fresh batch at every replay, nothing on the host), otherwise from torch's CPU generator
-    continued on the device: the reference's own ``ray_ids`` (``self.ray_ids``) followed by its jitter draw, the
-    generator left exactly where the reference's iteration leaves it.
+    ``train_imgs[ray_ids]`` gather) on the device.  With ``device_rng=True`` the selection is a node of graph A (counter RNG
+    keyed by seed + step, the step counter read from device memory): every replay selects the batch of the NEXT step
+    beside its own dX chain -- the selection depends on the counter only, never on the weights -- so it costs the step
+    nothing and nothing runs on the host; ``ray_ids`` (the rows the last step trained on) is recomputed on demand.
+    Otherwise the ids come from torch's CPU generator continued on the device: the reference's own ``ray_ids`` followed
+    by its jitter draw, the generator left exactly where the reference's iteration leaves it.
 
     ``check_every`` (default 16, 0 = never): every so many steps the forward's range flag is copied back without
     waiting; a later ``step`` raises FloatingPointError once such a copy shows non-finite values inside the network
@@ -475,8 +477,10 @@ class GraphedTrainStep:
         self.scratch = torch.empty(max(int(lib.nerf_amd_param_gradients_scratch_bytes(P)), 16), dtype=torch.uint8,
                                    device=dev)
         self.loss = torch.zeros((), **f32)
-        self.ray_ids = torch.zeros((B,), dtype=torch.int64, device=dev)        # rays_from: the batch's rows of the table
+        self._ids_next = torch.zeros((B,), dtype=torch.int64, device=dev)      # rays_from: rows of the table (see ray_ids)
+        self._ids_cur, self._ids_step, self._primed_for = torch.zeros_like(self._ids_next), -1, -1
         self._select_ws = torch.empty(max(int(lib.nerf_amd_select_workspace_bytes(B)), 256), dtype=torch.uint8, device=dev)
+        self._select_ws2 = torch.empty_like(self._select_ws)                    # eager selections beside the captured one
         import ctypes
         first, count = ctypes.c_int64(), ctypes.c_int64()
         self.buckets = []                                   # views of the flat gradient vector, in exchange order
@@ -507,11 +511,6 @@ class GraphedTrainStep:
         main = torch.cuda.current_stream(self.dev)
         side = self._side
         st, ss = ctypes_stream(main), ctypes_stream(side)
-        if self.rays_from is not None and self.device_rng:
-            # rg.select + the colour gather (train.py:47-49) as the first node: the step counter in device memory keys it
-            import ctypes
-            self.rays_from.launch(self.select_mode, B, None, self._select_seed(), ctypes.c_void_p(self.hyper.data_ptr() + 24),
-                                  self.rays, self.gt, self.ray_ids, stream=st, workspace=self._select_ws)
         side.wait_stream(main)
         if self.device_rng:
             # counter RNG; `u` = the address of this step's seed offset inside the hyper vector (int64 at float slot 6)
@@ -534,6 +533,14 @@ class GraphedTrainStep:
         ck(lib.nerf_amd_mse_loss(ptr(self.rgb), ptr(self.gt), ptr(self.loss), None, B * 3, ss), "nerf_amd_mse_loss")
         ck(lib.nerf_amd_param_gradients_begin(ptr(self.d_raw), ptr(self.scratch), ptr(self.grads), P, ss),
            "nerf_amd_param_gradients_begin")
+        if self.rays_from is not None and self.device_rng:
+            # rg.select + the colour gather (train.py:47-49) for the NEXT step, beside the dX chain: this step's rays and
+            # colours have been read for the last time (encoder rows, forward, compositor, loss), and the selection depends
+            # on the step counter only (device memory: every replay selects the batch of step + 1), never on the weights --
+            # so the first lines of the next iteration cost the step nothing.  step() primes the first batch.
+            import ctypes
+            self.rays_from.launch(self.select_mode, B, None, self._select_seed(1), ctypes.c_void_p(self.hyper.data_ptr() + 24),
+                                  self.rays, self.gt, self._ids_next, stream=ss, workspace=self._select_ws)
         ck(lib.nerf_amd_mlp_backward(ptr(self.d_raw), ptr(image), ptr(self.acts), ptr(self.dys), P, st),
            "nerf_amd_mlp_backward")
         main.wait_stream(side)
@@ -541,9 +548,29 @@ class GraphedTrainStep:
                                                       ptr(self.scratch), ptr(self.grads), P, bucket, st),
            "nerf_amd_param_gradients_finish_bucket")
 
-    def _select_seed(self):
-        # replicas (distinct ray_id0) must draw distinct batches
-        return (self.seed ^ (self.ray_id0 * 0x9E3779B97F4A7C15)) & 0xffffffffffffffff
+    def _select_seed(self, offset=0):
+        """The seed argument of nerf_amd_select_rays for the batch ``offset`` steps after the one the step counter in
+        device memory names: the kernel forms (seed ^ KEY) + counter, so the offset goes inside the key.  Replicas
+        (distinct ray_id0) draw distinct batches."""
+        from .utils.dataload import SELECT_KEY
+        m = 0xffffffffffffffff
+        base = (self.seed ^ (self.ray_id0 * 0x9E3779B97F4A7C15)) & m
+        return ((((base ^ SELECT_KEY) + int(offset)) & m) ^ SELECT_KEY) & m
+
+    def _select_now(self, step, rays, gt, ids):
+        """The batch of optimisation step ``step`` (1-based), eagerly: what the graph's prefetch produces one step ahead."""
+        self.rays_from.launch(self.select_mode, self.B, None, self._select_seed(step), None, rays, gt, ids, workspace=self._select_ws2)
+
+    @property
+    def ray_ids(self):
+        """Rows of the table the LAST step trained on (rays_from).  With the selection inside the graph the ids buffer
+        already holds the next batch's, so these are recomputed on demand (ids only: three small launches)."""
+        if self.rays_from is not None and self.device_rng:
+            if self._ids_step != self.opt.step_count:
+                self._select_now(self.opt.step_count, None, None, self._ids_cur)
+                self._ids_step = self.opt.step_count
+            return self._ids_cur
+        return self._ids_next
 
     def _head_gradients(self):
         """The second launch of the bucketed form: the products of layers_0.* (bucket 2)."""
@@ -639,7 +666,10 @@ class GraphedTrainStep:
             raise FloatingPointError(f"non-finite values inside the network in training step {bad[0]} ({what}): "
                                      "NaN / inf weights or inputs, the run has diverged")
         self._own_images()
-        select_in_graph = rays is None and self.device_rng
+        if rays is None and self.device_rng and self._primed_for != self.opt.step_count + 1:
+            # the first step (or one after the step counter was moved by hand): the graph prefetches batch k + 1 while
+            # step k runs, so batch k has to be there before the first replay
+            self._select_now(self.opt.step_count + 1, self.rays, self.gt, self._ids_next)
         if rays is not None:
             if self.rays_from is not None and self.device_rng:
                 raise RuntimeError("this GraphedTrainStep selects its rays inside the captured graph (rays_from, device_rng=True): "
@@ -654,12 +684,12 @@ class GraphedTrainStep:
             else:
                 from .utils import host_rng
                 if rays is None and host_rng.host_fallback():
-                    self.rays_from.select_batch(self.select_mode, self.B, out=(self.rays, self.gt, self.ray_ids))
+                    self.rays_from.select_batch(self.select_mode, self.B, out=(self.rays, self.gt, self._ids_next))
                 elif rays is None:
                     # the reference's iteration on torch's CPU stream, continued on the device: randperm(n)[:B] (the n - 1 - B
                     # draws nobody looks at are jumped over), the two gathers, then -- same stream -- the jitter draw
                     session = host_rng.GeneratorSession(self.dev)
-                    self.rays_from.select_from_session(session, self.select_mode, self.B, self.rays, self.gt, self.ray_ids,
+                    self.rays_from.select_from_session(session, self.select_mode, self.B, self.rays, self.gt, self._ids_next,
                                                        workspace=self._select_ws)
                 if u is None:
                     # the reference's one draw per call from torch's CPU generator, continued on the device; the generator is
@@ -682,10 +712,13 @@ class GraphedTrainStep:
         self.opt.step_count += 1
         self._set_hyper(self.opt.step_count)
         self.graph_a.replay()
+        if self.rays_from is not None and self.device_rng:
+            self._primed_for = self.opt.step_count + 1          # graph A left the next step's batch in the buffers
         if self.check_every and self.opt.step_count % self.check_every == 0:
             # behind the forward, in front of graph B's re-pack (which clears the flag for the next step)
             self._watch.push(self._packed_fwd, self.opt.step_count)
-            # the reference's |x| > 1 warning (utils/xyz.py:8-9) on this step's batch, verdict raised lazily
+            # the reference's |x| > 1 warning (utils/xyz.py:8-9) on the batch in the buffers (with the selection inside the
+            # graph that is already the next step's), verdict raised lazily
             from .utils.xyz import range_check_rays
             if self.device_rng:
                 import ctypes

@@ -18,6 +18,7 @@ import torch
 from .. import _lib
 from . import host_rng
 
+SELECT_KEY = 0x73656c6563743a31             # csrc/select.hip SEL_KEY: the selection's Philox stream, apart from the jitter's
 MAX_TABLE = 0xffffffff // 20                # torch.randperm switches algorithm at this length (randperm_cpu)
 
 
