@@ -373,6 +373,15 @@ int nerf_amd_mt19937_jump_poly(int64_t blocks, const uint32_t* h_phi624, uint32_
  * device: where torch.randperm(n) leaves the generator after its n - 1 draws, of which nerf_amd_select_rays looks at the
  * first B only.  All 32 bits of all 624 words are torch's.  One launch of 16 workgroups (~85 us). */
 int nerf_amd_mt19937_advance(const uint32_t* state624, const uint32_t* poly624, uint32_t* state_out624, void* stream);
+/* The jitter draw that FOLLOWS the shuffle in the reference's iteration (train.py:47-51: rg.select, then render_nerf's
+ * torch.rand(B, N) from the same generator) without a second dependent jump: out[n] = the n uniforms drawn from the state
+ * (1 + q) blocks after state624's block, read from word next_after on -- i.e. from where nerf_amd_mt19937_advance(q) would
+ * leave the generator -- with the start states of all `segments` = nerf_amd_mt19937_segments(next_after, n, seg_words) segments
+ * formed from state624 in ONE launch: polys[b][624] = x^(624 (q + b * seg_words / 624)) mod phi, b < segments
+ * (nerf_amd_mt19937_jump_poly).  state_out624: the state words after the draw; seg_states: workspace, segments * 624 words
+ * (seg_states[0] ends up holding the state after the shuffle). */
+int nerf_amd_mt19937_uniform_after(const uint32_t* state624, const uint32_t* polys, int segments, int next_after, float* out,
+                                   int64_t n, uint32_t* state_out624, int64_t seg_words, uint32_t* seg_states, void* stream);
 /* ray_ids = torch.randperm(n)[:B]; rays = table[ray_ids]; gt = colours[ray_ids]   (dataload.py:150-153, train.py:49) with
  * table[n,6] and colours[n,3] resident in HBM.  ids_out[B] (int64, as torch's), rays_out[B,6], gt_out[B,3]: any may be NULL.
  * The permutation prefix is the exact forward Fisher-Yates prefix of torch's CPU randperm (csrc/select.hip), from

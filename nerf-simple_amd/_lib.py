@@ -84,6 +84,7 @@ _SIGNATURES = {
     "nerf_amd_mt19937_raw": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "nerf_amd_mt19937_jump_poly": (_i32, [_i64, _vp, _vp]),
     "nerf_amd_mt19937_advance": (_i32, [_vp, _vp, _vp, _vp]),
+    "nerf_amd_mt19937_uniform_after": (_i32, [_vp, _vp, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
     "nerf_amd_select_workspace_bytes": (_i64, [_i64]),
     "nerf_amd_select_rays": (_i32, [_vp, _u64, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "nerf_amd_linear_f32": (_i32, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _u32, _vp]),

@@ -37,6 +37,8 @@ int nerf_amd_launch_mt19937_uniform_par(const uint32_t*, int, float*, long long,
                                         uint32_t*, hipStream_t);
 int nerf_amd_launch_range_check(const MlpArgs*, long long, unsigned*, hipStream_t);
 int nerf_amd_launch_mt19937_raw(const uint32_t*, int, uint32_t*, long long, uint32_t*, hipStream_t);
+int nerf_amd_launch_mt19937_uniform_after(const uint32_t*, const uint32_t*, int, int, float*, long long, uint32_t*, long long, uint32_t*,
+                                          hipStream_t);
 int nerf_amd_launch_mt19937_advance(const uint32_t*, const uint32_t*, uint32_t*, hipStream_t);
 int nerf_amd_launch_select_rays(const uint32_t*, unsigned long long, const unsigned long long*, long long, long long, const float*,
                                 const float*, float*, float*, long long*, void*, hipStream_t);
@@ -582,6 +584,16 @@ int nerf_amd_mt19937_jump_poly(int64_t blocks, const uint32_t* h_phi624, uint32_
 int nerf_amd_mt19937_advance(const uint32_t* state624, const uint32_t* poly624, uint32_t* state_out624, void* stream) {
     if (!state624 || !poly624 || !state_out624 || state624 == state_out624) return NERF_AMD_EINVAL;
     return nerf_amd_launch_mt19937_advance(state624, poly624, state_out624, S(stream));
+}
+
+int nerf_amd_mt19937_uniform_after(const uint32_t* state624, const uint32_t* polys, int segments, int next_after, float* out,
+                                   int64_t n, uint32_t* state_out624, int64_t seg_words, uint32_t* seg_states, void* stream) {
+    if (n <= 0 || segments < 1 || segments > 4096 || next_after < 0 || next_after > 624) return NERF_AMD_EINVAL;
+    if (seg_words <= 0 || seg_words % 624) return NERF_AMD_EINVAL;
+    if (!state624 || !polys || !out || !state_out624 || !seg_states) return NERF_AMD_EINVAL;
+    if (nerf_amd_mt19937_segments(next_after, n, seg_words) != segments) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_mt19937_uniform_after(state624, polys, segments, next_after, out, n, state_out624, seg_words, seg_states,
+                                                 S(stream));
 }
 
 int64_t nerf_amd_select_workspace_bytes(int64_t B) { return B < 0 ? NERF_AMD_EINVAL : align_up(B * 12 + 16, 256); }

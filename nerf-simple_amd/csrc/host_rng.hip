@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void mt19937_jump_kernel(unsigned* __restrict_
     if (third) atomicXor(dst + t + 512, a2);
 }
 
-__global__ void mt19937_zero_kernel(unsigned* __restrict__ words) { words[threadIdx.x] = 0u; }
+__global__ void mt19937_zero_kernel(unsigned* __restrict__ words) { words[blockIdx.x * blockDim.x + threadIdx.x] = 0u; }
 
 }  // namespace
 
@@ -264,6 +264,32 @@ extern "C" int nerf_amd_launch_mt19937_uniform(const uint32_t* state_in, int nex
     (void)hipGetLastError();
     hipLaunchKernelGGL(mt19937_uniform_kernel<float>, dim3(1), dim3(512), 0, stream, state_in, next, out, n, state_out,
                        (const unsigned*)nullptr, 0ll);
+    return (int)hipGetLastError();
+}
+
+// A draw that FOLLOWS a consumer nobody needs the numbers of (torch.rand(B, N) after torch.randperm(n): the reference's
+// training iteration): the start states of its S segments -- segment 0 included, i.e. the generator's state after the
+// skipped consumer -- come straight from the state BEFORE that consumer in ONE jump launch, jump distances summed:
+// polys[b] = x^(624 (q + b * seg_blocks)) mod phi, seg_states[b] = the block 1 + q + b * seg_blocks after state_in's.
+// (Jumping over the shuffle and then over the jitter's segments are two dependent launches of ~85 us each otherwise.)
+// next1 = first unread word of seg_states[0]'s block.
+extern "C" int nerf_amd_launch_mt19937_uniform_after(const uint32_t* state_in, const uint32_t* polys, int S, int next1,
+                                                     float* out, long long n, uint32_t* state_out, long long seg_words,
+                                                     uint32_t* seg_states, hipStream_t stream) {
+    (void)hipGetLastError();
+    const long long avail = MT_N - next1;
+    long long need = 1;
+    if (n > avail + seg_words) need = 1 + (n - avail - seg_words + seg_words - 1) / seg_words;
+    if (need != S) return -1;
+    hipLaunchKernelGGL(mt19937_zero_kernel, dim3((unsigned)S), dim3(MT_N), 0, stream, seg_states);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mt19937_jump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       MT_JUMP_LDS_MAX);
+    if (e != hipSuccess) return (int)e;
+    const int lds = (MT_JUMP_BLOCKS + 2) * MT_N * (int)sizeof(unsigned);
+    hipLaunchKernelGGL(mt19937_jump_kernel, dim3((unsigned)(S * MT_JUMP_SPLIT)), dim3(256), lds, stream, seg_states, polys, 0, 0, 0, 1, 1,
+                       state_in);
+    hipLaunchKernelGGL(mt19937_uniform_kernel<float>, dim3((unsigned)S), dim3(512), 0, stream, seg_states, next1, out, n, state_out,
+                       seg_states, seg_words);
     return (int)hipGetLastError();
 }
 

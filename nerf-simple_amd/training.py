@@ -689,9 +689,14 @@ class GraphedTrainStep:
                     # the reference's iteration on torch's CPU stream, continued on the device: randperm(n)[:B] (the n - 1 - B
                     # draws nobody looks at are jumped over), the two gathers, then -- same stream -- the jitter draw
                     session = host_rng.GeneratorSession(self.dev)
-                    self.rays_from.select_from_session(session, self.select_mode, self.B, self.rays, self.gt, self._ids_next,
-                                                       workspace=self._select_ws)
-                if u is None:
+                    drawn = self.rays_from.select_from_session(session, self.select_mode, self.B, self.rays, self.gt, self._ids_next,
+                                                               workspace=self._select_ws,
+                                                               jitter=(self.B, self.N, self.u) if u is None else None)
+                    if drawn is not None:
+                        u = self.u                       # the jitter came with the selection (one jump launch for both)
+                if u is self.u:
+                    pass
+                elif u is None:
                     # the reference's one draw per call from torch's CPU generator, continued on the device; the generator is
                     # made current again (session.finish: a wait for the generator kernels alone) once the whole step is
                     # enqueued behind it, so the host never waits for the previous step here

@@ -115,12 +115,19 @@ class RayGenerator:
         return rays, gt, ids
 
     # ---- pieces for callers that own the stream of draws (training.GraphedTrainStep) ---
-    def select_from_session(self, session, mode, B, rays, gt, ids, workspace=None):
+    def select_from_session(self, session, mode, B, rays, gt, ids, workspace=None, jitter=None):
         """The reference-stream selection inside an open ``host_rng.GeneratorSession`` (the jitter draw follows in the
-        same session, as render_nerf's torch.rand follows rg.select in train.py:47-51)."""
+        same session, as render_nerf's torch.rand follows rg.select in train.py:47-51).  ``jitter`` = (B, N, out): that
+        draw is made here too -- the generator's jump over the shuffle and the jump to the jitter's segments are then one
+        launch (``GeneratorSession.randperm_then_rand``) -- and returned."""
         n = int(self.rays_dataset[mode].shape[0])
-        draws = session.randperm_draws(n, B)
+        u = None
+        if jitter is not None:
+            draws, u = session.randperm_then_rand(n, B, jitter[0], jitter[1], out=jitter[2])
+        else:
+            draws = session.randperm_draws(n, B)
         self.launch(mode, B, draws, 0, None, rays, gt, ids, workspace=workspace)
+        return u
 
     def workspace(self, B, device):
         key = (int(B), str(device))

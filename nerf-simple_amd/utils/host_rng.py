@@ -168,6 +168,8 @@ class GeneratorSession:
         self.device = device
         self.state = torch.get_rng_state()
         self.left, _seeded, self.nxt, words = _parse(self.state)
+        # (a pinned staging ring for this 2.5 KB upload was tried: the host then runs ahead of the GPU and the graphed
+        # reference-stream iteration got SLOWER, 1.38 -> 2.01 ms; not understood, not kept)
         self.words_dev = torch.from_numpy(words.astype(np.uint32).view(np.int32)).to(device)
         self.changed = False                     # the words on the device are no longer the generator's
         self.event = None
@@ -226,6 +228,41 @@ class GeneratorSession:
             self._moved(state_out, left, nxt, blocks)
         return draws[:first]
 
+    def randperm_then_rand(self, n, B_sel, B, N, out=None):
+        """``torch.randperm(n)`` followed by ``torch.rand(B, N)`` -- the reference's rg.select and render_nerf's jitter draw
+        (train.py:47-51) -- as (first min(B_sel, n - 1) raw draws of the shuffle, u [B,N]).  For a large table the jump over
+        the shuffle's unused draws and the jump to the jitter's segment starts are ONE launch with summed distances
+        (nerf_amd_mt19937_uniform_after) instead of two dependent ones; otherwise the two calls above."""
+        n, B_sel, nj = int(n), int(B_sel), int(B) * int(N)
+        total = max(n - 1, 0)
+        left1, nxt1, blocks1 = _advance(self.left, self.nxt, total)
+        jp = _jump_polys(self.device)
+        if blocks1 <= _SEQUENTIAL_BLOCKS or nj == 0 or jp is None:
+            return self.randperm_draws(n, B_sel), self.rand(B, N, out=out)
+        short_words = jp[4]
+        next1 = _N + 1 - int(left1)
+        S = _segments(next1, nj, short_words)
+        if S > 256:
+            return self.randperm_draws(n, B_sel), self.rand(B, N, out=out)
+        lib = _lib.lib()
+        first = min(B_sel, total)
+        draws = torch.empty(max(first, 1), dtype=torch.int32, device=self.device)
+        u = torch.empty((B, N), dtype=torch.float32, device=self.device) if out is None else out
+        state_out = torch.empty(_N, dtype=torch.int32, device=self.device)
+        seg_states = torch.empty((S, _N), dtype=torch.int32, device=self.device)
+        polys = advance_poly_table(blocks1 - 1, short_words // _N, S, self.device)
+        left2, nxt2, _blocks2 = _advance(left1, nxt1, nj)
+        with torch.cuda.device(self.device):
+            st = _lib.stream_ptr(self.device)
+            _lib.check(lib.nerf_amd_mt19937_raw(_lib.ptr(self.words_dev), self._first_unread(), _lib.ptr(draws), first, None, st),
+                       "nerf_amd_mt19937_raw")
+            _lib.check(lib.nerf_amd_mt19937_uniform_after(_lib.ptr(self.words_dev), _lib.ptr(polys), S, next1, _lib.ptr(u), nj,
+                                                          _lib.ptr(state_out), short_words, _lib.ptr(seg_states), st),
+                       "nerf_amd_mt19937_uniform_after")
+            seg_states.record_stream(torch.cuda.current_stream(self.device))
+            self._moved(state_out, left2, nxt2, 1)          # the shuffle alone has regenerated: the words are new
+        return draws[:first], u
+
     def finish(self):
         """Make torch's generator current (a wait for the generator kernels only, not for what was enqueued behind them)."""
         if self.state is None:
@@ -262,6 +299,19 @@ def advance_poly(q, device):
             _advance_polys[host_key] = out
         _advance_polys[key] = torch.from_numpy(_advance_polys[host_key].view(np.int32)).to(device)
     return _advance_polys[key]
+
+
+_poly_tables = {}
+
+
+def advance_poly_table(q0, step, count, device):
+    """[count, 624] on ``device``: x^(624 (q0 + b * step)) mod phi, b < count (nerf_amd_mt19937_uniform_after)."""
+    key = (int(q0), int(step), int(count), str(device))
+    if key not in _poly_tables:
+        if len(_poly_tables) > 64:
+            _poly_tables.clear()
+        _poly_tables[key] = torch.stack([advance_poly(q0 + b * step, device) for b in range(count)]).contiguous()
+    return _poly_tables[key]
 
 
 class _Done:

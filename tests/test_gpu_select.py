@@ -113,18 +113,25 @@ def test_select_then_jitter_is_one_stream(dev):
     saved = torch.get_rng_state()
     try:
         torch.manual_seed(21)
-        for it in range(3):
+        for it in range(4):
             st = torch.get_rng_state()
             want_ids, want_u = torch.randperm(n)[:B], torch.rand(B, N)
             after = torch.get_rng_state()
             torch.set_rng_state(st)
-            session = H.GeneratorSession(dev)
-            out = (torch.empty((B, 6), device=dev), torch.empty((B, 3), device=dev), torch.empty(B, dtype=torch.int64, device=dev))
-            rg.select_from_session(session, "train", B, *out)
-            u = session.rand(B, N)
-            session.finish()
-            assert torch.equal(out[2].cpu(), want_ids) and torch.equal(u.cpu(), want_u), it
-            assert torch.equal(torch.get_rng_state(), after), it
+            for fused in (False, True):          # two dependent jumps (shuffle, jitter segments) / one with summed distances
+                torch.set_rng_state(st)
+                session = H.GeneratorSession(dev)
+                out = (torch.empty((B, 6), device=dev), torch.empty((B, 3), device=dev), torch.empty(B, dtype=torch.int64, device=dev))
+                if fused:
+                    buf = torch.full((B, N), -1.0, device=dev)
+                    u = rg.select_from_session(session, "train", B, *out, jitter=(B, N, buf))
+                    assert u is buf
+                else:
+                    rg.select_from_session(session, "train", B, *out)
+                    u = session.rand(B, N)
+                session.finish()
+                assert torch.equal(out[2].cpu(), want_ids) and torch.equal(u.cpu(), want_u), (it, fused)
+                assert torch.equal(torch.get_rng_state(), after), (it, fused)
     finally:
         torch.set_rng_state(saved)
 
