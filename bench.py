@@ -198,6 +198,48 @@ def pmc_traffic(kernel, mode, precision=None):
     return None, None
 
 
+def live_traffic(kernel, child_args, timeout=150):
+    """HBM bytes per launch of ``kernel``, MEASURED IN THIS RUN: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate
+    passes, as MI355X_MICROARCH.md's HBM section prescribes) over a 3-launch child run of this same script, then
+    WRITE_SIZE + 2 x FETCH_SIZE (KB; gfx950's wide-read correction).  Returns (bytes, note) or (None, reason): the caller
+    falls back to the committed summary.  The child is a separate process started with the program itself after `--`."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    work = tempfile.mkdtemp(prefix="nerf_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-aux"] + list(child_args)
+            env = dict(os.environ, TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "NERF_BENCH_FORCE_DIST"):
+                env.pop(k, None)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+            if r.returncode != 0:
+                return None, f"rocprofv3 pass {counter} failed (rc {r.returncode})"
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kernel in row.get("Kernel_Name", "").replace("(anonymous namespace)::", "") and row.get("Counter_Name") == counter:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, f"no {counter} rows for {kernel}"
+            vals[counter] = sum(got) / len(got)
+        return (vals["WRITE_SIZE"] + 2.0 * vals["FETCH_SIZE"]) * 1024.0, (
+            f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, {len(got)} launches each) of a child "
+            f"`bench.py --steps 2`: WRITE_SIZE {vals['WRITE_SIZE']:.0f} KB + 2 x FETCH_SIZE {vals['FETCH_SIZE']:.0f} KB")
+    except Exception as e:                                  # the number is evidence, not part of the contract: never fatal
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 _JSON_OUT = None
 
 
@@ -646,6 +688,17 @@ def run_render(args):
         achieved = launch_samples * FLOP_PER_SAMPLE / (kern_ms * 1e-3) / 1e12
         kern = RENDER_KERNEL[args.precision]
         traffic, traffic_src = pmc_traffic(kern, "render", args.precision) if not multi else (None, None)
+        traffic_kind = ("HBM bytes per launch from the committed rocprofv3 PMC passes of this command "
+                        "(WRITE_SIZE + 2 x FETCH_SIZE); not re-measured in this run")
+        if not multi and not args.no_aux and os.environ.get("NERF_BENCH_LIVE_PMC", "1") == "1":
+            live, note = live_traffic(kern, ["--precision", args.precision])
+            if live is not None:
+                stored = traffic
+                traffic, traffic_src, traffic_kind = live, "live", note
+                if stored:
+                    traffic_kind += f"; committed summary: {stored:.0f} B ({(live / stored - 1) * 100:+.1f} % against it)"
+            else:
+                traffic_kind += f" (live pass unavailable: {note})"
         res = {
             "metric": "ray-samples/sec at 800x800x128", "value": value, "unit": "ray-samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -670,8 +723,7 @@ def run_render(args):
             "roofline": {"bound": "mfma", "kernel": kern, "achieved": achieved, "peak": peak / 1e12,
                          "unit": "TFLOP/s", "frac": achieved * 1e12 / peak, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "traffic_kind": "HBM bytes per launch from the committed rocprofv3 PMC passes of this command "
-                                         "(WRITE_SIZE + 2 x FETCH_SIZE); not re-measured in this run",
+                         "traffic_kind": traffic_kind,
                          "algorithmic_hbm_bytes": nr * 40,
                          "kernel_ms": kern_ms, "flop_per_sample": FLOP_PER_SAMPLE,
                          "samples_per_launch": launch_samples},
@@ -792,6 +844,16 @@ def run_train(args):
         value = world * P * args.steps / elapsed
         achieved = DW_BYTES_PER_POINT * P / (dw_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic("dw_gemm_kernel(", "train") if not multi else (None, None)
+        traffic_kind = "HBM bytes per launch from the committed rocprofv3 PMC passes of this command; not re-measured in this run"
+        if not multi and not args.no_aux and os.environ.get("NERF_BENCH_LIVE_PMC", "1") == "1":
+            live, note = live_traffic("dw_gemm_kernel(", ["--mode", "train"])
+            if live is not None:
+                stored = traffic
+                traffic, traffic_src, traffic_kind = live, "live", note
+                if stored:
+                    traffic_kind += f"; committed summary: {stored:.0f} B ({(live / stored - 1) * 100:+.1f} % against it)"
+            else:
+                traffic_kind += f" (live pass unavailable: {note})"
         res = {
             "metric": "training ray-samples/sec (forward + backward + Adam) at 4096 rays x 64 samples per GPU",
             "value": value, "unit": "ray-samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -817,7 +879,7 @@ def run_train(args):
                            "head-gradient launch that runs beside the first exchange") if multi else None,
             "roofline": {"bound": "hbm", "kernel": "dw_gemm_kernel (timed: nerf_amd_param_gradients = zero fill + d_raw pack + dw_gemm)",
                          "achieved": achieved, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / PEAK_HBM,
-                         "traffic": traffic, "traffic_source": traffic_src, "kernel_ms": dw_ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": traffic_kind, "kernel_ms": dw_ms,
                          "algorithmic_bytes_per_point": DW_BYTES_PER_POINT,
                          "kernel_ms_note": "median of 20 extra launches on the step's own buffers after the timed region",
                          "step_mfma_frac": 3 * FLOP_PER_SAMPLE * P / (ms * 1e-3) / PEAK_BF16},

@@ -13,6 +13,9 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the reference's own warning on lego-scale points (utils/xyz.py:8-9), reproduced lazily: expected wherever a test renders
+    # a camera at radius 4; tests/test_gpu_boundary.py::test_range_warning_is_the_references looks at it on purpose
+    config.addinivalue_line("filterwarnings", "ignore:input not in range -1,1:UserWarning")
 
 
 @pytest.fixture(scope="session")
