@@ -8,7 +8,8 @@ if len(sys.argv) > 2 and sys.argv[1] == "--analyse":
         for r in csv.DictReader(open(f)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "")[:46]))
     rows.sort()
-    starts = [i for i, r in enumerate(rows) if "mt19937_uniform_kernel<unsigned" in r[2]]      # the shuffle's raw draws open an iteration
+    key = "adam_hyper_kernel" if "--counter" in sys.argv else "mt19937_uniform_kernel<unsigned"     # what opens / closes an iteration
+    starts = [i for i, r in enumerate(rows) if key in r[2]]
     a, b = starts[-4], starts[-3]
     t0 = rows[a][0]
     prev_end = rows[a - 1][1]
@@ -29,7 +30,7 @@ dev = torch.device("cuda:0")
 rg = bench.synthetic_ray_table(dev)
 net = Nerf(precision="bf16").to(dev)
 net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
-st = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), 4096, 64, rays_from=rg)
+st = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), 4096, 64, rays_from=rg, device_rng="--counter" in sys.argv, seed=3)
 torch.manual_seed(1)
 for _ in range(60):
     st.step()
