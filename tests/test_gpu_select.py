@@ -303,3 +303,41 @@ def test_integration_select_stub_from_the_document(dev, oracle):
     word = torch.tensor([9], dtype=torch.int64, device=dev)
     _, _, ids9 = ns["select"](table, colours, B, 5, step_word=word)
     assert np.array_equal(ids9.cpu().numpy(), oracle.select_ids_counter(n, B, 5, 9))
+
+
+def test_ray_generator_from_samples(dev, oracle, synthetic):
+    """RayGenerator.from_samples takes what the reference's load_data returns -- samples[mode] = [{'img': HxWx3 float64
+    array in [0,1], 'transform': 4x4 pose}], cam_params = [H, W, f] -- and builds rays_dataset (utils/dataload.py:114-129:
+    images in order, pixels row-major, [origin, R dir]) and the colour table (train.py:33 + .float()) on the device: origins
+    exact, directions within the fma rounding of the 3-term rotation (as test_generate_rays_golden), colours exact; a
+    select on it returns rows of those tables."""
+    from nerf_simple_amd.utils.dataload import RayGenerator
+    H, W = 12, 10
+    f = float(synthetic.focal_from_fov(W))
+    rng = np.random.default_rng(3)
+    samples = {"train": [], "val": []}
+    for mode, phis in (("train", (0.0, 40.0, 200.0)), ("val", (90.0,))):
+        for phi in phis:
+            samples[mode].append({"img": rng.random((H, W, 3)),                       # float64, as cv2 image / 255.0
+                                  "transform": torch.from_numpy(oracle.spherical_to_pose(4, -30, phi)).float()})
+    rg = RayGenerator.from_samples(samples, [H, W, f], device=dev)
+    assert (rg.H, rg.W) == (H, W) and set(rg.rays_dataset) == {"train", "val"}
+    for mode, items in samples.items():
+        want = torch.cat([oracle.camera_rays(s["transform"], [H, W, f]) for s in items])        # the reference's construction
+        got = rg.rays_dataset[mode].cpu()
+        assert got.shape == (len(items) * H * W, 6)
+        assert torch.equal(got[:, :3], want[:, :3])
+        assert float((got[:, 3:] - want[:, 3:]).abs().max()) <= 2.4e-7
+        train_imgs = torch.stack([torch.from_numpy(s["img"]) for s in items]).reshape(-1, 3)    # train.py:33
+        assert torch.equal(rg.colours[mode].cpu(), train_imgs.float())
+    saved = torch.get_rng_state()
+    try:
+        torch.manual_seed(2)
+        rays, gt, ids = rg.select_batch("train", 64)
+        torch.manual_seed(2)
+        assert torch.equal(ids.cpu(), torch.randperm(3 * H * W)[:64])
+    finally:
+        torch.set_rng_state(saved)
+    assert torch.equal(rays, rg.rays_dataset["train"][ids]) and torch.equal(gt, rg.colours["train"][ids])
+    with pytest.raises(RuntimeError):
+        RayGenerator({"train": rg.rays_dataset["train"].cpu()})                    # tables live on the GPU
