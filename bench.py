@@ -198,7 +198,7 @@ def pmc_traffic(kernel, mode, precision=None):
     return None, None
 
 
-def live_traffic(kernel, child_args, timeout=150):
+def live_traffic(kernel, child_args, timeout=100):
     """HBM bytes per launch of ``kernel``, MEASURED IN THIS RUN: two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- separate
     passes, as MI355X_MICROARCH.md's HBM section prescribes) over a 3-launch child run of this same script, then
     WRITE_SIZE + 2 x FETCH_SIZE (KB; gfx950's wide-read correction).  Returns (bytes, note) or (None, reason): the caller
