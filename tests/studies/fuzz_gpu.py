@@ -3,6 +3,8 @@
 
     python tests/studies/fuzz_gpu.py render     # 340 random (B, N <= 768, jitter mode) cases, three precisions:
                                         # the fused render kernel == MLP launch + compositor launch, bit for bit
+    python tests/studies/fuzz_gpu.py select     # 600 random (n, B <= n) selections, from collision-ridden tiny tables to 3e6
+                                        # rows: ids, rows and torch's generator afterwards == torch.randperm(n)[:B]
     python tests/studies/fuzz_gpu.py train      # 25 ragged (B, N) batches: fused training gradients vs the CPU oracle's
                                         # fp32 autograd under the test suite's stated bounds (tests/test_gpu_training.py)
 
@@ -90,7 +92,47 @@ def train():
 
 
 
+def select():
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import nerf_oracle as O
+    from nerf_simple_amd.utils.dataload import RayGenerator
+    dev = torch.device("cuda:0")
+    rng = np.random.Generator(np.random.PCG64(11))
+    bad = 0
+    saved = torch.get_rng_state()
+    for k in range(600):
+        kind = k % 4
+        n = int(rng.integers(1, 40)) if kind == 0 else int(rng.integers(40, 6000)) if kind == 1 else \
+            int(rng.integers(6000, 60000)) if kind == 2 else int(rng.integers(60000, 3_000_000))
+        B = n if rng.random() < 0.3 else int(rng.integers(1, min(n, 8192) + 1))
+        i = torch.arange(n, device=dev, dtype=torch.float32)
+        rays = torch.stack([i, -i, i * 0.5, i + 1, i + 2, i + 3], 1).contiguous()
+        cols = torch.stack([i, i + 0.5, -i], 1).contiguous()
+        rg = RayGenerator({"train": rays}, {"train": cols})
+        torch.manual_seed(int(rng.integers(0, 2 ** 31)))
+        pre = int(rng.integers(0, 1500))
+        if pre:
+            torch.rand(pre)
+        st = torch.get_rng_state()
+        want = torch.randperm(n)[:B]
+        after = torch.get_rng_state()
+        torch.set_rng_state(st)
+        r, g, ids = rg.select_batch("train", B)
+        ok = torch.equal(ids.cpu(), want) and torch.equal(torch.get_rng_state(), after) and torch.equal(r, rays[ids]) and torch.equal(g, cols[ids])
+        seed = int(rng.integers(0, 2 ** 40))
+        _, _, idc = rg.select_batch("train", B, device_rng=True, seed=seed)
+        okc = np.array_equal(idc.cpu().numpy(), O.select_ids_counter(n, B, seed)) if n <= 60000 else len(set(idc.tolist())) == B
+        if not (ok and okc):
+            bad += 1
+            print("MISMATCH", n, B, pre, ok, okc)
+    torch.set_rng_state(saved)
+    print("select sweep done, mismatches:", bad)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) != 2 or sys.argv[1] not in ("render", "train"):
+    if len(sys.argv) != 2 or sys.argv[1] not in ("render", "train", "select"):
         sys.exit(__doc__)
-    {"render": render, "train": train}[sys.argv[1]]()
+    {"render": render, "train": train, "select": select}[sys.argv[1]]()
