@@ -22,6 +22,7 @@ from .host_rng import ReferenceJitter, reference_rand
 from .nets import Nerf, guarded_launch
 
 ALL_OUTPUTS = ("rgb", "disp", "alpha", "acc", "w")
+_FUSED_MAX_N = 768          # csrc/nerf_layout.h FUSED_RENDER_MAX_N: rays the one-launch render composites in its LDS ring
 _tbins_cache = {}
 
 
@@ -200,6 +201,13 @@ def _render_batched(rays, net, batch_size, N, tn, tf, u, progress, id_base=0, **
     n = rays.size(0)
     rgb = torch.empty((n, 3), dtype=torch.float32, device=rays.device)
     disp = torch.empty((n,), dtype=torch.float32, device=rays.device)
+    if isinstance(net, Nerf) and net._fused_ok() and rays.is_cuda and 0 < n and N <= _FUSED_MAX_N:
+        # The reference's batch_size bounds the [batch, N, ...] tensors of its per-sample path.  The fused render keeps
+        # nothing per sample in HBM and its pixels do not depend on how the rays are batched (jitter rows follow the rays;
+        # bit for bit: tests/test_gpu_parity.py test_headline_workload_properties), so the image is ONE launch: 40 launches
+        # of 16,000 rays each end in a partly filled wave of tiles (+1.6 % at 800 x 800).  Longer rays (two-launch path,
+        # 20 B per sample of workspace) and foreign nets keep the caller's batches.
+        batch_size = n
     starts = range(0, n, batch_size)
     # The reference draws each batch's jitter inside render_nerf from the CPU generator: consecutive
     # pieces of one stream.  For the fused path they are all enqueued now on a side stream, so
