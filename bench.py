@@ -59,6 +59,8 @@ H = W = 800
 N_SAMPLES = 128
 TRAIN_RAYS, TRAIN_SAMPLES = 4096, 64   # per GPU (reference configs/lego.yaml:12; BASELINE config 5)
 DW_BYTES_PER_POINT = 11_776            # operands nerf_amd_param_gradients reads once per point
+DW_BYTES_PER_POINT_E4M3 = 5_856 + 368  # the same 15 products from 8-bit operands (d_raw rows 16 wide) + the conversion of the
+                                       # bf16 encoder rows and the packed d_raw (256 B read, 112 B written per point)
 # committed rocprofv3 PMC summaries (tools/profile_gpu.sh + tools/summarize_prof.py), newest first
 PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in
                  ("r04_bench_fp16_pmc.json", "r04_train_pmc.json", "r03_bench_fp16_pmc.json", "r03_bench_bf16_pmc.json", "r03_train_pmc.json",
@@ -73,6 +75,8 @@ def parse():
     ap.add_argument("--mode", default="render", choices=["render", "train"])
     ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
                     help="MFMA operand type of the render (train mode is bf16)")
+    ap.add_argument("--storage", default="e4m3", choices=["bf16", "e4m3"],
+                    help="train mode: how the saved activations and dY travel through HBM (GraphedTrainStep(storage=...))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary configurations (render mode, N=1)")
     ap.add_argument("--cpu-rays", type=int, default=16000,
@@ -804,7 +808,10 @@ def run_train(args):
     # in device memory: the replayed graphs carry no per-step argument); ray_id0 offsets each rank's draws
     stepper = GraphedTrainStep(net, opt, B, N, group=(dist.group.WORLD if multi else None), timing=multi,
                                buckets=int(os.environ.get("NERF_BENCH_BUCKETS", "1")), device_rng=True, seed=1234,
-                               ray_id0=rank * B, rays_from=rg)
+                               ray_id0=rank * B, rays_from=rg, storage=args.storage)
+    e4m3 = args.storage == "e4m3"
+    dw_kernel = "dw_gemm_e4m3_kernel(" if e4m3 else "dw_gemm_kernel("
+    dw_bytes = DW_BYTES_PER_POINT_E4M3 if e4m3 else DW_BYTES_PER_POINT
     decay = lr_decay_factor(5e-4, 5e-5, 10000)              # reference configs/lego.yaml lr_init / lr_final shape
     it = [0]
 
@@ -829,9 +836,16 @@ def run_train(args):
     for _ in range(20):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.check(lib.nerf_amd_param_gradients(_lib.ptr(stepper.d_raw), _lib.ptr(stepper.acts), _lib.ptr(stepper.dys),
-                                                _lib.ptr(stepper.posx), _lib.ptr(stepper.posd), _lib.ptr(stepper.scratch),
-                                                _lib.ptr(stepper.grads), P, st), "nerf_amd_param_gradients")
+        if e4m3:
+            _lib.check(lib.nerf_amd_param_gradients_begin(_lib.ptr(stepper.d_raw), _lib.ptr(stepper.scratch), _lib.ptr(stepper.grads), P, st),
+                       "nerf_amd_param_gradients_begin")
+            _lib.check(lib.nerf_amd_param_gradients_finish_e4m3(_lib.ptr(stepper.acts), _lib.ptr(stepper.dys), _lib.ptr(stepper.posx),
+                                                                _lib.ptr(stepper.posd), _lib.ptr(stepper.scratch), _lib.ptr(stepper.scratch8),
+                                                                _lib.ptr(stepper.grads), P, 0, st), "nerf_amd_param_gradients_finish_e4m3")
+        else:
+            _lib.check(lib.nerf_amd_param_gradients(_lib.ptr(stepper.d_raw), _lib.ptr(stepper.acts), _lib.ptr(stepper.dys),
+                                                    _lib.ptr(stepper.posx), _lib.ptr(stepper.posd), _lib.ptr(stepper.scratch),
+                                                    _lib.ptr(stepper.grads), P, st), "nerf_amd_param_gradients")
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize(dev)
@@ -842,11 +856,11 @@ def run_train(args):
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * P * args.steps / elapsed
-        achieved = DW_BYTES_PER_POINT * P / (dw_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic("dw_gemm_kernel(", "train") if not multi else (None, None)
+        achieved = dw_bytes * P / (dw_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dw_kernel, "train") if not multi else (None, None)
         traffic_kind = "HBM bytes per launch from the committed rocprofv3 PMC passes of this command; not re-measured in this run"
         if not multi and not args.no_aux and os.environ.get("NERF_BENCH_LIVE_PMC", "1") == "1":
-            live, note = live_traffic("dw_gemm_kernel(", ["--mode", "train"])
+            live, note = live_traffic(dw_kernel, ["--mode", "train", "--storage", args.storage])
             if live is not None:
                 stored = traffic
                 traffic, traffic_src, traffic_kind = live, "live", note
@@ -861,6 +875,9 @@ def run_train(args):
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "train.py step: 4096 rays x 64 samples per GPU, bf16, FusedAdam, hipGraph replay "
                                    "(BASELINE config 5)",
+                       "storage": ("saved activations and dY as e4m3 + one exponent per 32 features x 32 points (the dW products on the "
+                                   "block-scaled 8-bit MFMA); forward, loss and dX chain compute in bf16 as before" if e4m3 else
+                                   "saved activations and dY as bf16"),
                        "jitter": "fresh per step, device counter RNG inside the timed step",
                        "batch": f"fresh per step: rg.select + colour gather (train.py:47-49) from a {n_table}-ray table in HBM, "
                                 "inside the timed step (nodes of the replayed graph: each replay selects the next step's batch beside its dX chain)",
@@ -877,10 +894,11 @@ def run_train(args):
                            "two all-reduces of the flat gradient (1.27 MB, then 1.12 MB); collective_ms = from the end of the "
                            "late-layer gradient launch to both reduced, collective_exposed_ms = the part behind the end of the "
                            "head-gradient launch that runs beside the first exchange") if multi else None,
-            "roofline": {"bound": "hbm", "kernel": "dw_gemm_kernel (timed: nerf_amd_param_gradients = zero fill + d_raw pack + dw_gemm)",
+            "roofline": {"bound": "hbm", "kernel": dw_kernel.rstrip("(") + " (timed: nerf_amd_param_gradients = zero fill + d_raw pack" +
+                                   (" + conversion of the narrow operands" if e4m3 else "") + " + the products)",
                          "achieved": achieved, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / PEAK_HBM,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": traffic_kind, "kernel_ms": dw_ms,
-                         "algorithmic_bytes_per_point": DW_BYTES_PER_POINT,
+                         "algorithmic_bytes_per_point": dw_bytes,
                          "kernel_ms_note": "median of 20 extra launches on the step's own buffers after the timed region",
                          "step_mfma_frac": 3 * FLOP_PER_SAMPLE * P / (ms * 1e-3) / PEAK_BF16},
         }

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define NERF_AMD_ABI_VERSION 4
+#define NERF_AMD_ABI_VERSION 5
 
 /* error codes */
 #define NERF_AMD_EINVAL   (-1)   /* bad argument (null pointer, negative size, ...) */
@@ -309,6 +309,32 @@ int nerf_amd_param_gradients_finish(const void* acts, const void* dys, const voi
 int nerf_amd_grad_bucket_range(int bucket, int64_t* h_first, int64_t* h_count);
 int nerf_amd_param_gradients_finish_bucket(const void* acts, const void* dys, const void* posx64, const void* posd32,
                                            const void* scratch, float* grads, int64_t P, int bucket, void* stream);
+
+/* ---- the same three steps with the saved tensors in the 8-bit storage form ---------------------------------------
+ * What the forward saves and the dX chain writes is read by the weight gradients only: sums over all P points
+ * (reference train.py:54, loss.backward()).  With NERF_AMD_STORE_E4M3 both buffers hold OCP e4m3 bytes plus one
+ * power-of-two exponent per (32 features x 32 points) instead of bf16 -- half the bytes of the step's three
+ * HBM-bound kernels; the chain itself still runs on bf16 values in registers, so raw / d_raw / the masks are bit for
+ * bit those of the bf16 form, and the gradients differ by the operand rounding of the products only (bounded in
+ * tests/test_gpu_storage.py against the reference's minibatch deviation).
+ * Layout (csrc/nerf_layout.h): layer L at L * ceil(P/256) * 64 KiB, tile t at t * 64 KiB as
+ * [feature/16 (16)][point in tile (256)][16 x e4m3]; behind the 10 layers, per layer and 32-point block 8 exponent
+ * bytes (byte Q: features 32Q .. 32Q+31; value = e4m3 * 2^(byte - 127)); `acts` then carries the ReLU masks.
+ *   nerf_amd_mlp_forward_train(..., flags | NERF_AMD_STORE_E4M3, ...)  with acts of nerf_amd_train_activation_bytes_e4m3(P)
+ *   nerf_amd_mlp_backward_e4m3: dys of nerf_amd_train_gradient_bytes_e4m3(P)
+ *   nerf_amd_param_gradients_begin (unchanged: packs d_raw into `scratch`), then
+ *   nerf_amd_param_gradients_finish_e4m3: the 14 products on the block-scaled 8-bit MFMA; the bf16 encoder rows and the
+ *   packed d_raw are converted into `scratch_e4m3` (nerf_amd_param_gradients_scratch_e4m3_bytes(P)) by the call
+ *   (with buckets: by the call for bucket 0 or 1, which must come first). */
+#define NERF_AMD_STORE_E4M3 8u /* nerf_amd_mlp_forward_train only */
+int64_t nerf_amd_train_activation_bytes_e4m3(int64_t P);
+int64_t nerf_amd_train_gradient_bytes_e4m3(int64_t P);
+int64_t nerf_amd_param_gradients_scratch_e4m3_bytes(int64_t P);
+int nerf_amd_mlp_backward_e4m3(const float* d_raw, const void* bwd_image, const void* acts_e4m3,
+                               void* dys_e4m3, int64_t P, void* stream);
+int nerf_amd_param_gradients_finish_e4m3(const void* acts_e4m3, const void* dys_e4m3, const void* posx64,
+                                         const void* posd32, const void* scratch, void* scratch_e4m3,
+                                         float* grads, int64_t P, int bucket, void* stream);
 
 /* ---- loss: nn.MSELoss(), reference train.py:42,52 -------------------------------- */
 /* loss[0] = mean((pred - target)^2) over n elements; g_pred[n] (may be NULL) =

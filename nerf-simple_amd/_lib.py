@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libnerf_amd.so")
 
 F32, BF16, FP16, BF16_BWD = 0, 1, 2, 3
 FLAG_TS_GIVEN, FLAG_DEVICE_RNG, FLAG_SEED_IN_MEMORY = 1, 2, 4
+FLAG_STORE_E4M3 = 8          # nerf_amd_mlp_forward_train: the 8-bit storage form of the saved activations
 STATUS_NONFINITE, STATUS_WEIGHT_RANGE = 1, 2
 _PRECISIONS = {"fp32": F32, "f32": F32, "float32": F32, F32: F32,
                "bf16": BF16, "bfloat16": BF16, BF16: BF16,
@@ -71,6 +72,11 @@ _SIGNATURES = {
     "nerf_amd_train_activation_bytes": (_i64, [_i64]),
     "nerf_amd_mlp_forward_train": (_i32, [_vp, _vp, _vp, _vp, _u32, _u64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_mlp_backward": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "nerf_amd_train_activation_bytes_e4m3": (_i64, [_i64]),
+    "nerf_amd_train_gradient_bytes_e4m3": (_i64, [_i64]),
+    "nerf_amd_param_gradients_scratch_e4m3_bytes": (_i64, [_i64]),
+    "nerf_amd_mlp_backward_e4m3": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "nerf_amd_param_gradients_finish_e4m3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_sample_encode_bf16": (_i32, [_vp, _vp, _vp, _u32, _u64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_param_gradients_scratch_bytes": (_i64, [_i64]),
     "nerf_amd_param_gradients": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
@@ -119,7 +125,7 @@ def lib():
                 for name, (res, args) in _SIGNATURES.items():
                     fn = getattr(h, name)          # AttributeError if an export is missing
                     fn.restype, fn.argtypes = res, args
-                if h.nerf_amd_abi_version() != 4:
+                if h.nerf_amd_abi_version() != 5:
                     raise RuntimeError("libnerf_amd.so ABI version mismatch")
                 _lib = h
     return _lib

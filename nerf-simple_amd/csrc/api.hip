@@ -31,7 +31,10 @@ int nerf_amd_launch_sample_encode(const MlpArgs*, float*, float*, hipStream_t);
 int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f16_16(const MlpArgs*, int, hipStream_t);
-int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, long long, hipStream_t);
+int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, long long, int, hipStream_t);
+int nerf_amd_launch_param_gradients_finish_e4m3(const void*, const void*, const void*, const void*, const void*, void*, float*,
+                                                long long, int, hipStream_t);
+long long nerf_amd_f8_scratch_bytes(long long);
 int nerf_amd_launch_mt19937_uniform(const uint32_t*, int, float*, long long, uint32_t*, hipStream_t);
 int nerf_amd_launch_mt19937_uniform_par(const uint32_t*, int, float*, long long, uint32_t*, const uint32_t*, int, long long,
                                         uint32_t*, hipStream_t);
@@ -458,7 +461,8 @@ int nerf_amd_mlp_forward_train(const float* rays, const float* u, const float* t
     if (B < 0 || N <= 0) return NERF_AMD_EINVAL;
     if (B == 0) return 0;
     if (!rays || !packed || !raw || !acts) return NERF_AMD_EINVAL;
-    if (bad_jitter(flags, u, tbins)) return NERF_AMD_EINVAL;
+    if (bad_jitter(flags & ~NERF_AMD_STORE_E4M3, u, tbins)) return NERF_AMD_EINVAL;
+    static_assert(NERF_AMD_STORE_E4M3 == NERF_FLAG_STORE_E4M3, "the flag travels to the kernel as it is");
     MlpArgs a{};
     a.rays = rays; a.u = u; a.tbins = tbins; a.packed = packed; a.raw = raw; a.ts_out = ts; a.acts = acts;
     a.P = B * (int64_t)N; a.N = N; a.flags = flags; a.seed = seed; a.ray_id0 = ray_id0;
@@ -489,7 +493,32 @@ int nerf_amd_mlp_backward(const float* d_raw, const void* bwd_image, const void*
     if (P < 0) return NERF_AMD_EINVAL;
     if (P == 0) return 0;
     if (!d_raw || !bwd_image || !acts || !dys) return NERF_AMD_EINVAL;
-    return nerf_amd_launch_mlp_backward(d_raw, bwd_image, acts, dys, P, S(stream));
+    return nerf_amd_launch_mlp_backward(d_raw, bwd_image, acts, dys, P, 0, S(stream));
+}
+
+int64_t nerf_amd_train_activation_bytes_e4m3(int64_t P) {
+    return P < 0 ? (int64_t)NERF_AMD_EINVAL : (int64_t)f8_acts_total_bytes(P);
+}
+int64_t nerf_amd_train_gradient_bytes_e4m3(int64_t P) {
+    return P < 0 ? (int64_t)NERF_AMD_EINVAL : (int64_t)f8_data_bytes(P);
+}
+int64_t nerf_amd_param_gradients_scratch_e4m3_bytes(int64_t P) {
+    return P < 0 ? (int64_t)NERF_AMD_EINVAL : (int64_t)nerf_amd_f8_scratch_bytes(P);
+}
+int nerf_amd_mlp_backward_e4m3(const float* d_raw, const void* bwd_image, const void* acts, void* dys, int64_t P,
+                               void* stream) {
+    if (P < 0) return NERF_AMD_EINVAL;
+    if (P == 0) return 0;
+    if (!d_raw || !bwd_image || !acts || !dys) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_mlp_backward(d_raw, bwd_image, acts, dys, P, 1, S(stream));
+}
+int nerf_amd_param_gradients_finish_e4m3(const void* acts, const void* dys, const void* posx64, const void* posd32,
+                                         const void* scratch, void* scratch_e4m3, float* grads, int64_t P, int bucket,
+                                         void* stream) {
+    if (P < 0 || !grads || bucket < 0 || bucket > 2) return NERF_AMD_EINVAL;
+    if (P > 0 && (!acts || !dys || !posx64 || !posd32 || !scratch || !scratch_e4m3)) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_param_gradients_finish_e4m3(acts, dys, posx64, posd32, scratch, scratch_e4m3, grads, P, bucket,
+                                                       S(stream));
 }
 
 int nerf_amd_sample_encode_bf16(const float* rays, const float* u, const float* tbins, uint32_t flags,

@@ -133,6 +133,7 @@ struct State {
     int loff[NCB];                    // block_lane_offset(lane>>4, point in tile): this lane's granule of
                                       // fragment 0 in the tile's activation block; LOFF_INVALID past the end
     unsigned mb[NCB][2];              // ReLU mask bits being collected [column block][pair group]
+    unsigned amax[2];                 // 8-bit storage form: running |bf16| maximum of the fragment being finished (f8_absmax)
     long long mask_tile;              // byte offset of this tile's dword 0 of layer 0 (nerf_layout::mask_offset_bytes), uniform
     // fused render only (COMP)
     long long p_end;                  // one past this workgroup's last point (uniform)
@@ -181,7 +182,7 @@ struct Stage {
 // 2Q, 2Q+1; both column blocks): piece i -> column block i>>2, word i&3 of the
 // next layer's fragment Q.  Heads: (L8, Q=8) is the lone sigma tile, L10 the
 // rgb tile.
-template <int L, int Q, bool SAVE = false>
+template <int L, int Q, int SAVE = 0, int SLOT = 0>
 __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2], ex8 (&dst)[NCB][8], State& st) {
     constexpr LayerDesc D = layer_desc(L);
     const int cb = i >> 2, j2 = i & 3;   // i in [0, 4*NCB)
@@ -200,10 +201,25 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
         u32x4 w = __builtin_bit_cast(u32x4, dst[cb][Q]);
         w[j2] = pack2<D.relu != 0>(acc[cb][j2 >> 1][2 * (j2 & 1)], acc[cb][j2 >> 1][2 * (j2 & 1) + 1]);
         dst[cb][Q] = __builtin_bit_cast(ex8, w);
+        if constexpr (SAVE == 2) {
+            // 8-bit storage form: magnitudes are collected word by word; when both column blocks' fragments are
+            // complete the wave converts and writes them together (nerf_device.h store_fragment_f8)
+            // (SLOT: the pending pair of the previous chunk and this chunk's first pair can be in flight together)
+            st.amax[SLOT] = (i == 0) ? f8_absmax(0u, w[j2]) : f8_absmax(st.amax[SLOT], w[j2]);
+            if (i == 4 * NCB - 1) {
+                static_assert(NCB == 2, "store_fragment_f8 takes the two column blocks of a wave");
+                char* tb = st.acts + (f8_offset_bytes(L, st.P) + st.tile * F8_BLOCK_BYTES);
+                char* sp = st.acts + (f8_scale_offset_bytes(L, st.P) + st.tile * 64);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)F8_BLOCK_BYTES, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(sp, 0, 64, 0x00020000);
+                store_fragment_f8<2>(rs, st.loff[0], Q * 8192, rss, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6) * 8 + Q,
+                                     __builtin_bit_cast(u32x4, dst[0][Q]), w, st.amax[SLOT]);
+            }
+        }
         if constexpr (SAVE) {
             // the fragment is complete: write this lane's 2 x 4 features of layer L's output
             // (features 32Q+4g.. and 32Q+16+4g.. of its point) for the backward pass
-            if (j2 == 3) {
+            if (SAVE == 1 && j2 == 3) {
                 // Buffer stores into this (layer, tile)'s point-blocked block (nerf_layout.h),
                 // unconditional so the vector-memory instruction count per chunk is a constant
                 // (chunk_barrier); lanes past the last point carry an offset outside num_records.
@@ -238,32 +254,43 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
 }
 
 // vector-memory instructions epilogue_piece<L, Q, SAVE> issues over its 4*NCB pieces
-template <bool SAVE>
+template <int SAVE>
 __host__ __device__ constexpr int pair_vmem_ops(int L, int Q) {
     if (!SAVE || L < 0 || L == 10 || (L == 8 && Q == 8)) return 0;
     return NCB + ((layer_desc(L).relu != 0 && (Q & 3) == 3) ? NCB : 0);    // activations (+ a mask dword) per block
 }
 
 // the same summed over the pairs a chunk finishes itself (pairs P0 .. P0 + N - 1 of layer L)
-template <bool SAVE>
+template <int SAVE>
 __host__ __device__ constexpr int chunk_pair_vmem_ops(int L, int P0, int N) {
     int n = 0;
     for (int j = 0; j < N; ++j) n += pair_vmem_ops<SAVE>(L, P0 + j);
     return n;
 }
-template <bool SAVE>
+template <int SAVE>
 __host__ __device__ constexpr int vmem_before_barrier(int L, int PL, int PQ, int pair0, int npair_in, int pend_m0, int pend_per,
                                                       int pair_m0, int mt, int m_limit) {
     int n = 0;
     for (int cb = 0; cb < NCB; ++cb) {
-        if (PL >= 0 && pend_m0 + (4 * cb + 3) / pend_per < m_limit) n += pair_vmem_ops<SAVE>(PL, PQ) / NCB;
-        for (int j = 0; j < npair_in; ++j)
-            if (pair_m0 + j * 2 * mt + 4 * cb + 3 < m_limit) n += pair_vmem_ops<SAVE>(L, pair0 + j) / NCB;
+        // Column block cb's last piece (4 cb + 3) carries its mask dword and, in the bf16 form, its activation store; in
+        // the 8-bit form the wave's column blocks are converted and written together, by the pair's last piece (one
+        // data store + one exponent byte = NCB instructions: counted as one per column block, both at that piece).
+        const int own = 4 * cb + 3, data = SAVE == 2 ? 4 * NCB - 1 : own;
+        if (PL >= 0) {
+            const int ops = pair_vmem_ops<SAVE>(PL, PQ) / NCB;                    // 1, or 2 with a mask dword
+            if (ops > 0 && pend_m0 + data / pend_per < m_limit) n += 1;
+            if (ops > 1 && pend_m0 + own / pend_per < m_limit) n += ops - 1;
+        }
+        for (int j = 0; j < npair_in; ++j) {
+            const int ops = pair_vmem_ops<SAVE>(L, pair0 + j) / NCB;
+            if (ops > 0 && pair_m0 + j * 2 * mt + data < m_limit) n += 1;
+            if (ops > 1 && pair_m0 + j * 2 * mt + own < m_limit) n += ops - 1;
+        }
     }
     return n;
 }
 // epilogue piece `i` of in-chunk pair j (a compile-time pair index is needed: dispatch over the few values)
-template <int L, int P0, int N, bool SAVE, int J = 0>
+template <int L, int P0, int N, int SAVE, int J = 0>
 __device__ __forceinline__ void in_chunk_epilogue(int j, int i, const f32x4 (&acc)[NCB][2], ex8 (&dst)[NCB][8], State& st) {
     if constexpr (J < N) {
         if (j == J) epilogue_piece<L, P0 + J, SAVE>(i, acc, dst, st);
@@ -273,7 +300,7 @@ __device__ __forceinline__ void in_chunk_epilogue(int j, int i, const f32x4 (&ac
 
 // ---- one chunk: NT 16-row tiles of layer L starting at tile C * tpc(L) -------------------
 // PL/PQ: layer / pair of the pending accumulators handed over by the previous chunk.
-template <int L, int C, int PL, int PQ, bool SAVE>
+template <int L, int C, int PL, int PQ, int SAVE>
 __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NCB][8], ex8 (&out)[NCB][8]) {
     constexpr LayerDesc D = layer_desc(L);
     constexpr int KS_CHAIN = D.chain_k / 32;
@@ -397,8 +424,8 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
 #pragma unroll
                         for (int k = 0; k < PEND_PER; ++k) {
                             const int i = (m - PEND_M0) * PEND_PER + k;
-                            if constexpr (PL == L) epilogue_piece<PL, PQ, SAVE>(i, st.pend, out, st);
-                            else epilogue_piece<PL, PQ, SAVE>(i, st.pend, in, st);
+                            if constexpr (PL == L) epilogue_piece<PL, PQ, SAVE, 1>(i, st.pend, out, st);
+                            else epilogue_piece<PL, PQ, SAVE, 1>(i, st.pend, in, st);
                         }
                     }
                 }
@@ -434,12 +461,12 @@ __host__ __device__ constexpr int prev_pair(int L, int C) {
     return C > 0 ? C * tpc(L) / 2 - 1 : (L > 0 ? (L - 1 == 8 ? 8 : b16_mt(L - 1) / 2 - 1) : 0);
 }
 
-template <int L, bool SAVE, int... Cs>
+template <int L, int SAVE, int... Cs>
 __device__ __forceinline__ void run_layer_seq(const Ctx& c, State& st, ex8 (&in)[NCB][8], ex8 (&out)[NCB][8],
                                               std::integer_sequence<int, Cs...>) {
     (chunk_step<L, Cs, prev_layer(L, Cs), prev_pair(L, Cs), SAVE>(c, st, in, out), ...);
 }
-template <int L, bool SAVE>
+template <int L, int SAVE>
 __device__ __forceinline__ void run_layer(const Ctx& c, State& st, ex8 (&in)[NCB][8], ex8 (&out)[NCB][8]) {
     run_layer_seq<L, SAVE>(c, st, in, out, std::make_integer_sequence<int, layer_chunks(L)>{});
 }
@@ -453,7 +480,7 @@ __device__ __forceinline__ float enc_lane(TwoF q, int idx) {
 
 // SAVE (the training forward, launched in rays mode) also serves Nerf.forward(v) with gradients:
 // a.pts != NULL switches the point fetch at run time, so training needs no third instantiation.
-template <bool RAYS, bool SAVE, bool COMP>
+template <bool RAYS, int SAVE, bool COMP>
 __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, long long tile_base, State& st) {
     const int col = c.lane & 15, g = c.lane >> 4;
     // Counter-RNG jitter: the four lane groups of a point would each evaluate the same Philox
@@ -510,6 +537,12 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
         long long p = tile_base + c.wave * (16 * NCB) + cb * 16 + col;
         const bool valid = p < p_end;
         st.loff[cb] = valid ? block_lane_offset(g, c.wave * (16 * NCB) + cb * 16 + col) : LOFF_INVALID;
+        if constexpr (SAVE == 2) {
+            // 8-bit form: after store_fragment_f8's transpose the lane writes the granule of point 16 (lane >> 5) + col of
+            // the wave, not of its own two points
+            if (cb == 0)
+                st.loff[0] = tile_base + c.wave * 32 + 16 * (c.lane >> 5) + col < p_end ? f8_lane_offset(c.lane, c.wave) : LOFF_INVALID;
+        }
         if (!valid) p = p_end - 1;
         PointIn pt;
         st.posd_off[cb] = c.b_posd + cb * 1024;              // per-sample form: this lane's own fragment
@@ -570,7 +603,7 @@ __device__ __forceinline__ void stage_inputs(const Ctx& c, const MlpArgs& a, lon
 }
 
 // one tile: prologue (sampling / RNG / encoding into LDS) + the 11 layers; leaves st.rgb / st.sigma
-template <bool RAYS, bool SAVE, bool COMP>
+template <bool RAYS, int SAVE, bool COMP>
 __device__ __forceinline__ void run_tile(const Ctx& c, const MlpArgs& a, long long tile_base, State& st) {
     stage_inputs<RAYS, SAVE, COMP>(c, a, tile_base, st);
     run_layer<0, SAVE>(c, st, st.X, st.X);
@@ -612,11 +645,9 @@ struct RingSamples {                         // a ray's samples in the workgroup
     }
 };
 
-template <bool RAYS, bool SAVE, bool COMP>
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, long long ntiles) {
+template <bool RAYS, int SAVE, bool COMP>
+__device__ __forceinline__ void kernel_body(const MlpArgs& a, long long ntiles) {
     static_assert(!COMP || (RAYS && !SAVE), "the fused render is the rays-mode inference kernel");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    (void)smem;
     Ctx c;
     c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.lane = threadIdx.x & 63;
@@ -657,7 +688,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
             st.wf = &wf;
             st.acts = reinterpret_cast<char*>(a.acts);
             st.P = a.P;
-            st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
+            st.mask_tile = SAVE == 2 ? f8_mask_offset_bytes(0, tile, 0, a.P) : mask_offset_bytes(0, tile, 0, a.P);
             st.tile = tile;
             st.bad = false;
             run_tile<RAYS, SAVE, false>(c, a, tile_base, st);
@@ -732,6 +763,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, 
     }
 }
 
+template <bool RAYS, bool SAVE, bool COMP>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void NERF_KERNEL(MlpArgs a, long long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)smem;
+    kernel_body<RAYS, SAVE ? 1 : 0, COMP>(a, ntiles);
+}
+#ifndef NERF_HALF
+// the training forward with the 8-bit storage form of the saved activations (nerf_layout.h; MlpArgs::flags bit
+// NERF_FLAG_STORE_E4M3): a kernel of its own name, so the bf16-storage instantiations keep theirs
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_train_e4m3_kernel(MlpArgs a, long long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)smem;
+    kernel_body<true, 2, false>(a, ntiles);
+}
+#endif
+
 }  // namespace
 
 extern "C" int NERF_LAUNCH(const MlpArgs* args, int rays_mode, hipStream_t stream) {
@@ -758,7 +805,8 @@ extern "C" int NERF_LAUNCH(const MlpArgs* args, int rays_mode, hipStream_t strea
     auto kern = rays_mode ? NERF_KERNEL<true, false, false> : NERF_KERNEL<false, false, false>;
 #else
     if (a.acts && !rays_mode) return -2;          // the training forward is the rays-mode instantiation (a.pts selects points)
-    auto kern = a.acts ? NERF_KERNEL<true, true, false>
+    if ((a.flags & NERF_FLAG_STORE_E4M3) && !a.acts) return -2;
+    auto kern = a.acts ? ((a.flags & NERF_FLAG_STORE_E4M3) ? nerf_mlp_train_e4m3_kernel : NERF_KERNEL<true, true, false>)
                        : (rays_mode ? NERF_KERNEL<true, false, false> : NERF_KERNEL<false, false, false>);
 #endif
     e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_TOTAL);

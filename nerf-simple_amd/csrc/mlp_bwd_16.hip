@@ -32,6 +32,7 @@ struct BwdArgs {
     const char* acts;         // saved forward activations
     char* dys;                // out: pre-activation gradients, same layout as acts
     long long P;
+    int store_e4m3;           // acts (its masks) and dys are in the 8-bit storage form (nerf_layout.h)
 };
 
 namespace {
@@ -90,6 +91,7 @@ struct State {
     char* dys;
     long long P, tile;
     int loff[2];                    // block_lane_offset(lane>>4, point in tile), LOFF_INVALID past the end
+    unsigned amax[2];               // 8-bit storage form: running |bf16| maximum of the fragment being finished
 };
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -122,7 +124,7 @@ __device__ __forceinline__ void load_mask(const State& st, u32x4& m) {
 
 // piece i of the epilogue of pair Q of backward layer B: mask, convert, and (on the
 // fragment's last word) store dY of forward layer 9-B
-template <int B, int Q>
+template <int B, int Q, bool F8, int SLOT = 0>
 __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], ex8 (&dst)[2][8], State& st) {
     constexpr BwdDesc D = bwd_desc(B);
     constexpr int LOUT = 9 - B;
@@ -138,7 +140,18 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
     u32x4 w = __builtin_bit_cast(u32x4, dst[cb][Q]);
     w[j2] = pack2(v0, v1);
     dst[cb][Q] = __builtin_bit_cast(ex8, w);
-    if (j2 == 3) {
+    if constexpr (F8) {
+        // 8-bit storage form: both column blocks' fragments are converted and written together (store_fragment_f8)
+        st.amax[SLOT] = (i == 0) ? f8_absmax(0u, w[j2]) : f8_absmax(st.amax[SLOT], w[j2]);
+        if (i == 7) {
+            char* tb = st.dys + (f8_offset_bytes(LOUT, st.P) + st.tile * F8_BLOCK_BYTES);
+            char* sp = st.dys + (f8_scale_offset_bytes(LOUT, st.P) + st.tile * 64);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)F8_BLOCK_BYTES, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(sp, 0, 64, 0x00020000);
+            store_fragment_f8<2>(rs, st.loff[0], Q * 8192, rss, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6) * 8 + Q,
+                                 __builtin_bit_cast(u32x4, dst[0][Q]), w, st.amax[SLOT]);
+        }
+    } else if (j2 == 3) {
         // one 16-byte granule per lane into the (layer, tile) block of dY, after trading 8-byte
         // pieces with lane group g ^ 1; unconditional buffer store (forward epilogue_piece)
         char* tb = st.dys + (act_offset_bytes(LOUT, st.P) + st.tile * ACT_BLOCK_BYTES);
@@ -147,7 +160,7 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
     }
 }
 
-template <int B, int C, int PB, int PQ>
+template <int B, int C, int PB, int PQ, bool F8>
 __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8]) {
     constexpr BwdDesc D = bwd_desc(B);
     constexpr int KS_CHAIN = D.chain_k / 32;
@@ -216,8 +229,8 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
 #pragma unroll
                         for (int k = 0; k < PEND_PER; ++k) {
                             const int i = (m - PEND_M0) * PEND_PER + k;
-                            if constexpr (PB == B) epilogue_piece<PB, PQ>(i, st.pend, out, st);
-                            else epilogue_piece<PB, PQ>(i, st.pend, in, st);
+                            if constexpr (PB == B) epilogue_piece<PB, PQ, F8, 1>(i, st.pend, out, st);
+                            else epilogue_piece<PB, PQ, F8, 1>(i, st.pend, in, st);
                         }
                     }
                 }
@@ -225,7 +238,7 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
                     const f32x4 pr[2][2] = {{acc[0][0], acc[0][1]}, {acc[1][0], acc[1][1]}};
 #pragma unroll
                     for (int k = 0; k < PAIR_PER; ++k)
-                        epilogue_piece<B, 2 * C>((m - PAIR_M0) * PAIR_PER + k, pr, out, st);
+                        epilogue_piece<B, 2 * C, F8>((m - PAIR_M0) * PAIR_PER + k, pr, out, st);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -251,19 +264,18 @@ __host__ __device__ constexpr int prev_layer(int b, int C) { return C > 0 ? b : 
 __host__ __device__ constexpr int prev_pair(int b, int C) {
     return C > 0 ? 2 * C - 1 : (b > 0 ? bwd_mt(b - 1) / 2 - 1 : 0);
 }
-template <int B, int... Cs>
+template <int B, bool F8, int... Cs>
 __device__ __forceinline__ void run_layer_seq(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8],
                                               std::integer_sequence<int, Cs...>) {
-    (chunk_step<B, Cs, prev_layer(B, Cs), prev_pair(B, Cs)>(c, st, in, out), ...);
+    (chunk_step<B, Cs, prev_layer(B, Cs), prev_pair(B, Cs), F8>(c, st, in, out), ...);
 }
-template <int B>
+template <int B, bool F8>
 __device__ __forceinline__ void run_layer(const Ctx& c, State& st, ex8 (&in)[2][8], ex8 (&out)[2][8]) {
-    run_layer_seq<B>(c, st, in, out, std::make_integer_sequence<int, layer_chunks(B)>{});
+    run_layer_seq<B, F8>(c, st, in, out, std::make_integer_sequence<int, layer_chunks(B)>{});
 }
 
-__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(BwdArgs a, long long ntiles) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    (void)smem;
+template <bool F8>
+__device__ __forceinline__ void bwd_body(const BwdArgs& a, long long ntiles) {
     Ctx c;
     c.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     c.lane = threadIdx.x & 63;
@@ -287,7 +299,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(Bwd
         st.acts = a.acts;
         st.dys = a.dys;
         st.P = a.P;
-        st.mask_tile = mask_offset_bytes(0, tile, 0, a.P);
+        st.mask_tile = F8 ? f8_mask_offset_bytes(0, tile, 0, a.P) : mask_offset_bytes(0, tile, 0, a.P);
         st.tile = tile;
         load_mask<bwd_desc(0).mask_act>(st, st.mk[0]);
         const __bf16 z = (__bf16)0.f;
@@ -295,6 +307,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(Bwd
         for (int cb = 0; cb < 2; ++cb) {
             const long long p = tile_base + c.wave * 32 + cb * 16 + col;
             st.loff[cb] = p < a.P ? block_lane_offset(g, c.wave * 32 + cb * 16 + col) : LOFF_INVALID;
+            if (F8 && cb == 0)      // the lane writes the granule of point 16 (lane >> 5) + col of the wave (store_fragment_f8)
+                st.loff[0] = tile_base + c.wave * 32 + 16 * (c.lane >> 5) + col < a.P ? f8_lane_offset(c.lane, c.wave) : LOFF_INVALID;
             f32x4 d = {0.f, 0.f, 0.f, 0.f};
             if (p < a.P) d = *reinterpret_cast<const f32x4*>(a.d_raw + p * 4);
             // custom k-steps: lane group 0 carries drgb (elements 0..2) / dsigma (element 0)
@@ -302,34 +316,47 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(Bwd
             st.bx_rgb[cb] = ex8{g0 ? (__bf16)d[0] : z, g0 ? (__bf16)d[1] : z, g0 ? (__bf16)d[2] : z, z, z, z, z, z};
             st.bx_sig[cb] = ex8{g0 ? (__bf16)d[3] : z, z, z, z, z, z, z, z};
         }
-        run_layer<0>(c, st, st.X, st.X);     // d c    (b0 reads only drgb)        -> X[.][0..3]
-        run_layer<1>(c, st, st.X, st.Y);     // d h9
-        run_layer<2>(c, st, st.Y, st.X);     // d h8
-        run_layer<3>(c, st, st.X, st.Y);     // d h7
-        run_layer<4>(c, st, st.Y, st.X);     // d h6
-        run_layer<5>(c, st, st.X, st.Y);     // d h5
-        run_layer<6>(c, st, st.Y, st.X);     // d h4
-        run_layer<7>(c, st, st.X, st.Y);     // d h3
-        run_layer<8>(c, st, st.Y, st.X);     // d h2
-        run_layer<9>(c, st, st.X, st.Y);     // d h1
+        run_layer<0, F8>(c, st, st.X, st.X);     // d c    (b0 reads only drgb)        -> X[.][0..3]
+        run_layer<1, F8>(c, st, st.X, st.Y);     // d h9
+        run_layer<2, F8>(c, st, st.Y, st.X);     // d h8
+        run_layer<3, F8>(c, st, st.X, st.Y);     // d h7
+        run_layer<4, F8>(c, st, st.Y, st.X);     // d h6
+        run_layer<5, F8>(c, st, st.X, st.Y);     // d h5
+        run_layer<6, F8>(c, st, st.Y, st.X);     // d h4
+        run_layer<7, F8>(c, st, st.X, st.Y);     // d h3
+        run_layer<8, F8>(c, st, st.Y, st.X);     // d h2
+        run_layer<9, F8>(c, st, st.X, st.Y);     // d h1
         // the last pair of d h1 is still pending
 #pragma unroll
-        for (int i = 0; i < 8; ++i) epilogue_piece<9, bwd_mt(9) / 2 - 1>(i, st.pend, st.Y, st);
+        for (int i = 0; i < 8; ++i) epilogue_piece<9, bwd_mt(9) / 2 - 1, F8>(i, st.pend, st.Y, st);
     }
+}
+
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_kernel(BwdArgs a, long long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)smem;
+    bwd_body<false>(a, ntiles);
+}
+// the same chain writing dY in the 8-bit storage form (and reading the masks behind an 8-bit activation buffer)
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nerf_mlp_bwd_e4m3_kernel(BwdArgs a, long long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    (void)smem;
+    bwd_body<true>(a, ntiles);
 }
 
 }  // namespace
 
 extern "C" int nerf_amd_launch_mlp_backward(const float* d_raw, const void* image, const void* acts, void* dys,
-                                            long long P, hipStream_t stream) {
+                                            long long P, int store_e4m3, hipStream_t stream) {
     (void)hipGetLastError();
     if (P <= 0) return 0;
-    BwdArgs a{d_raw, image, reinterpret_cast<const char*>(acts), reinterpret_cast<char*>(dys), P};
+    BwdArgs a{d_raw, image, reinterpret_cast<const char*>(acts), reinterpret_cast<char*>(dys), P, store_e4m3};
     const long long ntiles = (P + TILE_PTS - 1) / TILE_PTS;
     const int cus = device_cus();
     const long long grid = ntiles < cus ? ntiles : cus;
-    const hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(nerf_mlp_bwd_kernel), LDS_TOTAL);
+    auto kern = store_e4m3 ? nerf_mlp_bwd_e4m3_kernel : nerf_mlp_bwd_kernel;
+    const hipError_t e = allow_dynamic_lds(reinterpret_cast<const void*>(kern), LDS_TOTAL);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(nerf_mlp_bwd_kernel, dim3((unsigned)grid), dim3(WAVES * 64), LDS_TOTAL, stream, a, ntiles);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(WAVES * 64), LDS_TOTAL, stream, a, ntiles);
     return (int)hipGetLastError();
 }

@@ -19,6 +19,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define NERF_FLAG_TS_GIVEN 1u
 #define NERF_FLAG_DEVICE_RNG 2u
 #define NERF_FLAG_SEED_IN_MEMORY 4u     // with DEVICE_RNG: `u` is the device address of a uint64 added to `seed` at run time
+#define NERF_FLAG_STORE_E4M3 8u         // training forward: save the activations in the 8-bit storage form (nerf_layout.h)
 
 // Arguments of the fused sampling + encoding + MLP kernels.
 struct MlpArgs {
@@ -122,6 +123,66 @@ __device__ __forceinline__ void store_granule(__amdgpu_buffer_rsrc_t rs, int vof
     const unsigned o0 = s0[0], o1 = s1[0], o2 = s0[1], o3 = s1[1];
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{o0, o1, o2, o3}, rs, voffset, soffset, AUX);
     asm volatile("s_nop 1" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
+}
+
+// ---- 8-bit storage form (nerf_layout.h): one 32-feature fragment of the wave's 32 points -> e4m3 + its exponent ---------
+// Running maximum of the magnitudes of the packed bf16 pairs of a fragment (both column blocks): one AND + one packed
+// unsigned maximum per word -- a non-negative bf16 orders like its bit pattern.
+__device__ __forceinline__ unsigned f8_absmax(unsigned running, unsigned word) {
+    const u16x2 a = __builtin_bit_cast(u16x2, running), b = __builtin_bit_cast(u16x2, word & 0x7fff7fffu);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(a, b));
+}
+template <int CTRL>
+__device__ __forceinline__ unsigned f8_max_dpp(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
+    return o > v ? o : v;
+}
+// w0 / w1: the fragment's four packed words of column block 0 / 1 (word j = features 32Q + 16 (j >> 1) + 4 g + 2 (j & 1)
+// + {0, 1} of the lane's point, g = lane >> 4); amax: f8_absmax over the eight words.  The wave agrees on the exponent of
+// its largest magnitude (DPP inside the 16-lane rows, four v_readlane across them), every pair is divided by
+// 2^(exponent - 7) and rounded to e4m3 by v_cvt_scalef32_pk_fp8_bf16 (round to nearest even; the largest value lands in
+// [128, 256), so nothing reaches e4m3's 448), and a 4 x 4 transpose of the lanes' four dwords across the lane groups
+// (two v_permlane32_swap + two v_permlane16_swap) leaves lane group g with ONE whole 16-byte granule: groups 0 / 1 =
+// chunks 2Q / 2Q+1 of points 0..15 of the wave, groups 2 / 3 the same chunks of points 16..31.  One dwordx4 store per
+// lane -- 512 contiguous bytes per chunk -- and one byte store of the exponent by lane 0: two vector-memory
+// instructions per fragment, as in the bf16 form (the counted waits of the chunk barrier do not change).
+//   rs_data: the (layer, tile) block; voff = f8_lane_offset(lane, wave) or LOFF_INVALID; soff_data = Q * 8192.
+//   rs_scale: the tile's 64 exponent bytes of this layer; byte wave * 8 + Q is written.
+__host__ __device__ constexpr int f8_lane_offset(int lane, int wave) {
+    return ((lane >> 4) & 1) * 4096 + (wave * 32 + 16 * (lane >> 5) + (lane & 15)) * 16;
+}
+template <int AUX = 0>
+__device__ __forceinline__ void store_fragment_f8(__amdgpu_buffer_rsrc_t rs_data, int voff, int soff_data,
+                                                  __amdgpu_buffer_rsrc_t rs_scale, int lane, int scale_byte,
+                                                  u32x4 w0, u32x4 w1, unsigned amax) {
+    unsigned m = (amax >> 16) > (amax & 0xffffu) ? (amax >> 16) : (amax & 0xffffu);
+    m = f8_max_dpp<0xB1>(m);             // quad_perm [1,0,3,2]
+    m = f8_max_dpp<0x4E>(m);             // quad_perm [2,3,0,1]
+    m = f8_max_dpp<0x141>(m);            // row_half_mirror
+    m = f8_max_dpp<0x140>(m);            // row_mirror: every lane of a row holds the row's maximum
+    const unsigned r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
+    const unsigned r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
+    const unsigned r01 = r0 > r1 ? r0 : r1, r23 = r2 > r3 ? r2 : r3;
+    const int e = (int)((r01 > r23 ? r01 : r23) >> 7);            // biased exponent of the largest |bf16| (sign bit cleared)
+    const int sb = e > 8 ? e - 7 : 1;                             // e8m0 byte of the block; >= 1 so the divisor is a normal float
+    const float scale = __builtin_bit_cast(float, sb << 23);
+    s16x2 t = {0, 0};
+    auto cvt = [&](unsigned lo, unsigned hi) -> unsigned {
+        t = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(t, __builtin_bit_cast(bf16x2, lo), scale, false);
+        t = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(t, __builtin_bit_cast(bf16x2, hi), scale, true);
+        return __builtin_bit_cast(unsigned, t);
+    };
+    const unsigned a0 = cvt(w0[0], w0[1]), b0 = cvt(w0[2], w0[3]), a1 = cvt(w1[0], w1[1]), b1 = cvt(w1[2], w1[3]);
+    // lane group g holds piece g of four granules (a0: chunk 2Q of its cb-0 point, b0: chunk 2Q+1, a1 / b1: the cb-1
+    // point); after the transpose it holds pieces 0..3 of granule g
+    const auto x0 = __builtin_amdgcn_permlane32_swap(a0, a1, false, false);
+    const auto x1 = __builtin_amdgcn_permlane32_swap(b0, b1, false, false);
+    const auto y0 = __builtin_amdgcn_permlane16_swap(x0[0], x1[0], false, false);
+    const auto y1 = __builtin_amdgcn_permlane16_swap(x0[1], x1[1], false, false);
+    const unsigned o0 = y0[0], o1 = y0[1], o2 = y1[0], o3 = y1[1];
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{o0, o1, o2, o3}, rs_data, voff, soff_data, AUX);
+    asm volatile("s_nop 1" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");      // store_granule's hazard
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_scale, lane == 0 ? scale_byte : LOFF_INVALID, 0, 0);
 }
 
 template <int N>

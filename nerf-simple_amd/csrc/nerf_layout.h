@@ -256,6 +256,38 @@ NL_HD constexpr long long mask_offset_bytes(int L, long long tile, int dword, lo
 }
 NL_HD constexpr long long acts_total_bytes(long long P) { return acts_bf16_bytes(P) + 10 * mask_tiles(P) * 8192; }
 
+// ---- 8-bit storage form of the same two buffers (training step, storage = e4m3) ------------------------------------------
+// What the forward saves for dW and what the dX chain writes for it can be stored as OCP e4m3 with one power-of-two
+// exponent per (32 features x 32 points): dW_l = dY_l^T X_l and db_l are sums over ~10^5..10^6 points, the only readers,
+// and the rounding of their operands stays inside the gradient criterion (the chain itself keeps
+// bf16 in registers).  Half the bytes of the step's three HBM-bound kernels.
+//   data: per layer, per tile of 256 points a 64 KiB block [feature chunk c = f/16 (16)][point in tile (256)][16 x e4m3];
+//         the 32 points of a wave write 512 contiguous bytes per chunk, the dW kernel reads 64-point runs of 1 KiB;
+//   exponents: per layer, per 32-point block (one MLP wave) 8 bytes, byte Q = biased power-of-two exponent s (e8m0: the
+//         stored byte b means value = e4m3(b) * 2^(s - 127)) of features 32Q .. 32Q+31 -- the block scale of
+//         v_mfma_scale_f32_32x32x64_f8f6f4, chosen so that the largest magnitude lands in [128, 256);
+//   (acts only) the ReLU masks, unchanged, behind them.
+// Narrow operands of the dW products (encoder rows, the packed d_raw) use the same form with their own chunk count.
+constexpr long long F8_BLOCK_BYTES = 256 * 256;
+constexpr int F8_SCALE_BYTES_PER_BLOCK = 8;
+NL_HD constexpr long long f8_layer_stride(long long P) { return act_tiles(P) * F8_BLOCK_BYTES; }
+NL_HD constexpr long long f8_offset_bytes(int L, long long P) { return (long long)L * f8_layer_stride(P); }
+NL_HD constexpr long long f8_elem_offset(int L, long long p, int f, long long P) {
+    return f8_offset_bytes(L, P) + (p / ACT_TILE_PTS) * F8_BLOCK_BYTES + ((long long)(f / 16) * ACT_TILE_PTS + p % ACT_TILE_PTS) * 16 + f % 16;
+}
+NL_HD constexpr long long f8_scale_layer_stride(long long P) { return act_tiles(P) * (ACT_TILE_PTS / 32) * F8_SCALE_BYTES_PER_BLOCK; }
+NL_HD constexpr long long f8_scale_offset_bytes(int L, long long P) { return 10 * f8_layer_stride(P) + (long long)L * f8_scale_layer_stride(P); }
+NL_HD constexpr long long f8_data_bytes(long long P) { return 10 * f8_layer_stride(P) + 10 * f8_scale_layer_stride(P); }   // dY buffer
+NL_HD constexpr long long f8_mask_region_offset(long long P) { return (f8_data_bytes(P) + 255) / 256 * 256; }
+NL_HD constexpr long long f8_mask_offset_bytes(int L, long long tile, int dword, long long P) {
+    return f8_mask_region_offset(P) + (((long long)L * mask_tiles(P) + tile) * 4 + dword) * 2048;
+}
+NL_HD constexpr long long f8_acts_total_bytes(long long P) { return f8_mask_region_offset(P) + 10 * mask_tiles(P) * 8192; }
+// a narrow operand of W features (W % 16 == 0): [tile][chunk (W/16)][point (256)][16 B], then its exponents [block][8]
+NL_HD constexpr long long f8_narrow_block_bytes(int W) { return (long long)(W / 16) * ACT_TILE_PTS * 16; }
+NL_HD constexpr long long f8_narrow_scale_offset(int W, long long P) { return act_tiles(P) * f8_narrow_block_bytes(W); }
+NL_HD constexpr long long f8_narrow_bytes(int W, long long P) { return f8_narrow_scale_offset(W, P) + f8_scale_layer_stride(P); }
+
 // ---- packed f32 image -----------------------------------------------------
 // 16-row output tiles (mfma_f32_16x16x4f32).  chunk = (layer, t): K/4 k-steps
 // x 64 lanes x 4 B, stored [ks/4][lane][4] so one ds_read_b128 per lane covers

@@ -420,13 +420,19 @@ class GraphedTrainStep:
     Otherwise the ids come from torch's CPU generator continued on the device: the reference's own ``ray_ids`` followed
     by its jitter draw, the generator left exactly where the reference's iteration leaves it.
 
+    ``storage='e4m3'``: what the forward saves for the weight gradients and what the dX chain writes for them travels
+    through HBM as 8-bit floats with one power-of-two exponent per 32 features x 32 points instead of bf16 (half the
+    bytes of the step's three HBM-bound kernels; the dW products run on the block-scaled 8-bit MFMA).  The forward's
+    outputs, the loss and d_raw are bit for bit those of the default; the gradients carry the operands' 8-bit rounding,
+    inside the same criterion (a fraction of the reference's own minibatch deviation; tests/test_gpu_storage.py).
+
     ``check_every`` (default 16, 0 = never): every so many steps the forward's range flag is copied back without
     waiting; a later ``step`` raises FloatingPointError once such a copy shows non-finite values inside the network
     (NaN / inf weights or inputs: a diverged run) -- the reference would show a NaN loss there.
     """
 
     def __init__(self, net, optimizer, n_rays, N, *, tn=2, tf=6, group=None, timing=False, buckets=1,
-                 device_rng=False, seed=0, ray_id0=0, check_every=16, rays_from=None, select_mode="train"):
+                 device_rng=False, seed=0, ray_id0=0, check_every=16, rays_from=None, select_mode="train", storage="bf16"):
         from . import parallel
         from .optim import FusedAdam
         from .utils.rendering import _tbins
@@ -445,6 +451,9 @@ class GraphedTrainStep:
         self.device_rng, self.seed, self.ray_id0 = bool(device_rng), int(seed), int(ray_id0)
         self.check_every, self._watch = int(check_every), _StatusWatch()
         self.B, self.N = int(n_rays), int(N)
+        if storage not in ("bf16", "e4m3"):
+            raise ValueError("storage must be 'bf16' (the default) or 'e4m3'")
+        self.storage, self._e4m3 = storage, storage == "e4m3"
         dev = optimizer.flat.device
         self.dev = dev
         self.rays_from, self.select_mode = rays_from, select_mode
@@ -466,9 +475,14 @@ class GraphedTrainStep:
         self.tbins = _tbins(tn, tf, N_, dev)
         self.raw = torch.empty((B, N_, 4), **f32)
         self.ts = torch.empty((B, N_), **f32)
-        nb = int(lib.nerf_amd_train_activation_bytes(P))
-        self.acts = torch.empty(nb, dtype=torch.uint8, device=dev)
-        self.dys = torch.empty(nb, dtype=torch.uint8, device=dev)
+        if self._e4m3:
+            self.acts = torch.empty(int(lib.nerf_amd_train_activation_bytes_e4m3(P)), dtype=torch.uint8, device=dev)
+            self.dys = torch.empty(int(lib.nerf_amd_train_gradient_bytes_e4m3(P)), dtype=torch.uint8, device=dev)
+            self.scratch8 = torch.empty(max(int(lib.nerf_amd_param_gradients_scratch_e4m3_bytes(P)), 16), dtype=torch.uint8, device=dev)
+        else:
+            nb = int(lib.nerf_amd_train_activation_bytes(P))
+            self.acts = torch.empty(nb, dtype=torch.uint8, device=dev)
+            self.dys = torch.empty(nb, dtype=torch.uint8, device=dev)
         self.posx = torch.empty((P, 64), dtype=torch.bfloat16, device=dev)
         self.posd = torch.empty((P, 32), dtype=torch.bfloat16, device=dev)
         self.rgb = torch.empty((B, 3), **f32)
@@ -523,7 +537,8 @@ class GraphedTrainStep:
         ck(lib.nerf_amd_sample_encode_bf16(ptr(self.rays), jit, ptr(self.tbins), flags, seed, rid,
                                            ptr(self.posx), ptr(self.posd), None, B, N_, ss),
            "nerf_amd_sample_encode_bf16")
-        ck(lib.nerf_amd_mlp_forward_train(ptr(self.rays), jit, ptr(self.tbins), ptr(packed), flags, seed, rid,
+        ck(lib.nerf_amd_mlp_forward_train(ptr(self.rays), jit, ptr(self.tbins), ptr(packed),
+                                          flags | (_lib.FLAG_STORE_E4M3 if self._e4m3 else 0), seed, rid,
                                           ptr(self.raw), ptr(self.ts), ptr(self.acts), B, N_, st),
            "nerf_amd_mlp_forward_train")
         # only rgb feeds the loss (train.py:52): disparity, alpha, acc, w are not materialised
@@ -541,12 +556,22 @@ class GraphedTrainStep:
             import ctypes
             self.rays_from.launch(self.select_mode, B, None, self._select_seed(1), ctypes.c_void_p(self.hyper.data_ptr() + 24),
                                   self.rays, self.gt, self._ids_next, stream=ss, workspace=self._select_ws)
-        ck(lib.nerf_amd_mlp_backward(ptr(self.d_raw), ptr(image), ptr(self.acts), ptr(self.dys), P, st),
-           "nerf_amd_mlp_backward")
+        backward = lib.nerf_amd_mlp_backward_e4m3 if self._e4m3 else lib.nerf_amd_mlp_backward
+        ck(backward(ptr(self.d_raw), ptr(image), ptr(self.acts), ptr(self.dys), P, st), "nerf_amd_mlp_backward")
         main.wait_stream(side)
-        ck(lib.nerf_amd_param_gradients_finish_bucket(ptr(self.acts), ptr(self.dys), ptr(self.posx), ptr(self.posd),
-                                                      ptr(self.scratch), ptr(self.grads), P, bucket, st),
-           "nerf_amd_param_gradients_finish_bucket")
+        self._finish(bucket, st)
+
+    def _finish(self, bucket, st):
+        """The dW products (all, or one bucket's) from the saved tensors in this step's storage form."""
+        lib, ptr, P = _lib.lib(), _lib.ptr, self.B * self.N
+        if self._e4m3:
+            _lib.check(lib.nerf_amd_param_gradients_finish_e4m3(ptr(self.acts), ptr(self.dys), ptr(self.posx), ptr(self.posd),
+                                                                ptr(self.scratch), ptr(self.scratch8), ptr(self.grads), P, bucket, st),
+                       "nerf_amd_param_gradients_finish_e4m3")
+        else:
+            _lib.check(lib.nerf_amd_param_gradients_finish_bucket(ptr(self.acts), ptr(self.dys), ptr(self.posx), ptr(self.posd),
+                                                                  ptr(self.scratch), ptr(self.grads), P, bucket, st),
+                       "nerf_amd_param_gradients_finish_bucket")
 
     def _select_seed(self, offset=0):
         """The seed argument of nerf_amd_select_rays for the batch ``offset`` steps after the one the step counter in
@@ -574,10 +599,7 @@ class GraphedTrainStep:
 
     def _head_gradients(self):
         """The second launch of the bucketed form: the products of layers_0.* (bucket 2)."""
-        P = self.B * self.N
-        _lib.check(_lib.lib().nerf_amd_param_gradients_finish_bucket(
-            _lib.ptr(self.acts), _lib.ptr(self.dys), _lib.ptr(self.posx), _lib.ptr(self.posd), _lib.ptr(self.scratch),
-            _lib.ptr(self.grads), P, 2, _lib.stream_ptr(self.dev)), "nerf_amd_param_gradients_finish_bucket")
+        self._finish(2, _lib.stream_ptr(self.dev))
 
     def _update(self):
         lib, opt = _lib.lib(), self.opt

@@ -69,7 +69,8 @@ def fused_step(dev, synthetic, rays, gt, u, N, graphed):
     net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
     opt = FusedAdam(net, lr=5e-4)
     if graphed:
-        stepper = GraphedTrainStep(net, opt, rays.shape[0], N)
+        # graphed == "e4m3": the 8-bit storage form of the saved activations / dY (tests/test_gpu_storage.py)
+        stepper = GraphedTrainStep(net, opt, rays.shape[0], N, storage="e4m3" if graphed == "e4m3" else "bf16")
         loss = float(stepper.step(rays.to(dev), gt.to(dev), u=u.to(dev)))
     else:
         loss = float(train_step(net, opt, rays.to(dev), gt.to(dev), N, u=u.to(dev)))
@@ -105,7 +106,7 @@ def check_step_fixture(g, loss, grads, post, tag):
     return worst
 
 
-@pytest.mark.parametrize("graphed", [False, True])
+@pytest.mark.parametrize("graphed", [False, True, "e4m3"])
 def test_train_step_golden_n128(dev, golden, synthetic, oracle, graphed):
     """G6b: 64 rays x Nf = 128 (the reference's sample count, train.py:51 / configs/lego.yaml:6) through the fused
     bf16 kernels, eager and as captured hipGraphs; then all 24 gradients against the oracle with the derived bound:
@@ -132,12 +133,12 @@ def test_train_step_golden_n128(dev, golden, synthetic, oracle, graphed):
         mean = stack.mean(0)
         s_k = float(torch.sqrt(((stack - mean) ** 2).sum() / 3) / mean.norm())
         ratios[k] = rel_l2(grads[k].numpy(), want[k].numpy()) / s_k
-    print(f"G6b {'graphed' if graphed else 'eager'}: worst stored-slice rel L2 {worst:.3e}; worst e/s {max(ratios.values()):.3f} "
+    print(f"G6b {('graphed ' + str(graphed)) if graphed else 'eager'}: worst stored-slice rel L2 {worst:.3e}; worst e/s {max(ratios.values()):.3f} "
           f"({max(ratios, key=ratios.get)})")
     assert max(ratios.values()) <= GRAD_NOISE_RATIO, ratios
 
 
-@pytest.mark.parametrize("graphed", [False, True])
+@pytest.mark.parametrize("graphed", [False, True, "e4m3"])
 def test_train_step_reference_config(dev, golden, synthetic, oracle, graphed):
     """G6c: one step at the reference's REAL shape -- batch_size 4096, Nf 128 (configs/lego.yaml:6,12) -- with the
     rays selected as RayGenerator.select does (utils/dataload.py:150-153).  Fixture values (loss, norms, stored
@@ -160,7 +161,7 @@ def test_train_step_reference_config(dev, golden, synthetic, oracle, graphed):
     ratios = {k: rel_l2(grads[k].numpy(), want[k].numpy()) / (float(g[f"mbstd/{k}"]) / fpc) for k in want}
     for k, v in ratios.items():
         print(f"    {k:28s} e {rel_l2(grads[k].numpy(), want[k].numpy()):.3e}  e/s {v:.3f}")
-    print(f"G6c {'graphed' if graphed else 'eager'}: worst e/s {max(ratios.values()):.3f} ({max(ratios, key=ratios.get)})")
+    print(f"G6c {('graphed ' + str(graphed)) if graphed else 'eager'}: worst e/s {max(ratios.values()):.3f} ({max(ratios, key=ratios.get)})")
     assert max(ratios.values()) <= GRAD_NOISE_RATIO, ratios
     # direction and length of every tensor's gradient, separately (a relative L2 bound alone would let a tensor
     # trade one for the other)
@@ -199,9 +200,11 @@ def run_trajectory(dev, golden, oracle, synthetic, mode, seed_index=0, precision
         opt = FusedAdam(net, lr=5e-4)                       # torch.optim.Adam(net.parameters(), lr=5e-4), train.py:43
         # "*_select": the first two lines of the iteration (rg.select and the colour gather, train.py:47-49) run on the
         # device too, from tables resident in HBM (utils/dataload.RayGenerator): nothing of the loop is left on the host
-        on_device = mode.endswith("_select")
+        # "*_e4m3": the saved activations and dY in the 8-bit storage form (tests/test_gpu_storage.py)
+        storage = "e4m3" if mode.endswith("_e4m3") else "bf16"
+        on_device = "_select" in mode
         rg = RayGenerator.from_tables(rays_tab, gt_tab, device=dev) if on_device else None
-        stepper = GraphedTrainStep(net, opt, B, N, rays_from=rg) if mode.startswith("graphed") else None
+        stepper = GraphedTrainStep(net, opt, B, N, rays_from=rg, storage=storage) if mode.startswith("graphed") else None
         losses, vals, snaps = [], [val_mse(net)], {}
         torch.manual_seed(seed)
         for i in range(K):
@@ -261,7 +264,7 @@ def test_training_trajectory_exact_fp32(dev, golden, oracle, synthetic):
     assert max(perr.values()) <= EXACT_PARAM_RTOL, perr
 
 
-@pytest.mark.parametrize("mode", ["eager", "graphed", "eager_select", "graphed_select"])
+@pytest.mark.parametrize("mode", ["eager", "graphed", "eager_select", "graphed_select", "graphed_select_e4m3"])
 def test_training_trajectory(dev, golden, oracle, synthetic, mode):
     """G8: 60 iterations of the reference's loop (train.py:45-57) with the fused bf16 kernels, same seed as the
     reference run -- so the same rays and the same jitter at every step, and torch's CPU generator ends at the same
