@@ -75,7 +75,7 @@ def parse():
     ap.add_argument("--mode", default="render", choices=["render", "train"])
     ap.add_argument("--precision", default="fp16", choices=["bf16", "fp16", "fp32"],
                     help="MFMA operand type of the render (train mode is bf16)")
-    ap.add_argument("--storage", default="e4m3", choices=["bf16", "e4m3"],
+    ap.add_argument("--storage", default="bf16", choices=["bf16", "e4m3"],
                     help="train mode: how the saved activations and dY travel through HBM (GraphedTrainStep(storage=...))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the auxiliary configurations (render mode, N=1)")
@@ -624,6 +624,16 @@ def aux_configs(dev, sd, rays_800):
                               "step_mfma_frac": 3 * FLOP_PER_SAMPLE * P / (ms * 1e-3) / PEAK_BF16, "peak_tflops": PEAK_BF16 / 1e12,
                               "final_loss": float(stepper.loss), "steps": steps}
         del stepper, net
+        # the same iteration with the saved activations and dY in the 8-bit storage form (same gradient criterion:
+        # tests/test_gpu_trajectory.py)
+        net = net_of("bf16", 0, "default")
+        stepper = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), TRAIN_RAYS, N, device_rng=True, seed=7, rays_from=rg, storage="e4m3")
+        ms8 = event_timed(stepper.step, steps, 30, dev)
+        aux["c5"][f"N{N}"]["storage_e4m3"] = {
+            "ms": ms8, "ray_samples_per_s": P / (ms8 * 1e-3), "final_loss": float(stepper.loss), "steps": steps,
+            "kernel": "... + nerf_mlp_train_e4m3_kernel + composite_backward_kernel + nerf_mlp_bwd_e4m3_kernel + rows_to_e4m3_kernel + dw_gemm_e4m3_kernel + ...",
+            "what": "saved activations and dY as e4m3 + one exponent per 32 features x 32 points; dW products on the block-scaled 8-bit MFMA"}
+        del stepper, net
     del rg
     return aux
 
@@ -826,6 +836,26 @@ def run_train(args):
 
     elapsed = timed_loop(step, args, dist, dev, world)
     coll = stepper.collective_times() if multi else None      # (span, exposed) ms per timed step
+    # the other storage form of the saved tensors, timed alike in the same process (N = 1): a second module from the same
+    # initial weights, its own optimizer and graphs, the same table and seeds
+    other = None
+    if not multi and not args.no_aux:
+        o_storage = "bf16" if e4m3 else "e4m3"
+        onet = Nerf(precision="bf16").to(dev)
+        onet.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
+        ost = GraphedTrainStep(onet, FusedAdam(onet, lr=5e-4), B, N, device_rng=True, seed=1234, ray_id0=rank * B, rays_from=rg,
+                               storage=o_storage)
+        for _ in range(args.warmup):
+            ost.step(decay=decay)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ost.step(decay=decay)
+        torch.cuda.synchronize(dev)
+        o_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        other = {"storage": o_storage, "ms_per_step": o_ms, "value": P / (o_ms * 1e-3), "steps": args.steps, "warmup": args.warmup,
+                 "final_loss": float(ost.loss)}
+        del ost, onet
     seen = ranks_seen(dist, dev, world)
     loss = float(stepper.loss)
     # duration of the dominant kernel (dW + db, nerf_amd_param_gradients): 20 more launches on the same
@@ -885,6 +915,12 @@ def run_train(args):
                        "rays_per_gpu": B, "samples_per_ray": N, "global_batch_rays": B * world,
                        "parallelism": f"data-parallel x{world}" + (" + all_reduce of the flat 2.38 MB gradient" if multi else "")},
             "ranks": seen, "final_loss": loss,
+            "by_storage": (None if other is None else {
+                args.storage: {"headline": True, "ms_per_step": ms, "value": value, "steps": args.steps, "warmup": args.warmup,
+                               "final_loss": loss},
+                other["storage"]: {k: v for k, v in other.items() if k != "storage"},
+                "criterion": "both forms pass the same gradient criterion (every tensor's error <= half the reference's minibatch "
+                             "deviation, fixture G6c) and the 60-iteration trajectory bands: tests/test_gpu_trajectory.py"}),
             "kernel_ms_per_rank": dw_ms_ranks,
             "collective_ms": max(span_ranks) if multi else 0.0,
             "collective_exposed_ms": max(exposed_ranks) if multi else 0.0,

@@ -273,9 +273,13 @@ __global__ __launch_bounds__(256) void rows_to_e4m3_kernel(const __bf16* __restr
         w0 = sp[0];
         w1 = sp[1];
     }
+    // magnitudes of packed bf16 pairs order like their bit patterns with the sign cleared
     unsigned m = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { m = f8_absmax(m, w0[k]); m = f8_absmax(m, w1[k]); }
+    for (int k = 0; k < 4; ++k) {
+        const u16x2 x = __builtin_bit_cast(u16x2, w0[k] & 0x7fff7fffu), y = __builtin_bit_cast(u16x2, w1[k] & 0x7fff7fffu);
+        m = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(u16x2, m), __builtin_elementwise_max(x, y)));
+    }
     unsigned mx = (m >> 16) > (m & 0xffffu) ? (m >> 16) : (m & 0xffffu);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {

@@ -133,7 +133,7 @@ struct State {
     int loff[NCB];                    // block_lane_offset(lane>>4, point in tile): this lane's granule of
                                       // fragment 0 in the tile's activation block; LOFF_INVALID past the end
     unsigned mb[NCB][2];              // ReLU mask bits being collected [column block][pair group]
-    unsigned amax[2];                 // 8-bit storage form: running |bf16| maximum of the fragment being finished (f8_absmax)
+    float amax[2];                    // 8-bit storage form: running maximum of the fragment being finished (f8_absmax)
     long long mask_tile;              // byte offset of this tile's dword 0 of layer 0 (nerf_layout::mask_offset_bytes), uniform
     // fused render only (COMP)
     long long p_end;                  // one past this workgroup's last point (uniform)
@@ -205,7 +205,7 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
             // 8-bit storage form: magnitudes are collected word by word; when both column blocks' fragments are
             // complete the wave converts and writes them together (nerf_device.h store_fragment_f8)
             // (SLOT: the pending pair of the previous chunk and this chunk's first pair can be in flight together)
-            st.amax[SLOT] = (i == 0) ? f8_absmax(0u, w[j2]) : f8_absmax(st.amax[SLOT], w[j2]);
+            st.amax[SLOT] = f8_absmax<D.relu == 0>(i == 0 ? 0.f : st.amax[SLOT], acc[cb][j2 >> 1][2 * (j2 & 1)], acc[cb][j2 >> 1][2 * (j2 & 1) + 1]);
             if (i == 4 * NCB - 1) {
                 static_assert(NCB == 2, "store_fragment_f8 takes the two column blocks of a wave");
                 char* tb = st.acts + (f8_offset_bytes(L, st.P) + st.tile * F8_BLOCK_BYTES);

@@ -91,7 +91,7 @@ struct State {
     char* dys;
     long long P, tile;
     int loff[2];                    // block_lane_offset(lane>>4, point in tile), LOFF_INVALID past the end
-    unsigned amax[2];               // 8-bit storage form: running |bf16| maximum of the fragment being finished
+    float amax[2];                  // 8-bit storage form: running maximum of the fragment being finished (f8_absmax)
 };
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -142,7 +142,7 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
     dst[cb][Q] = __builtin_bit_cast(ex8, w);
     if constexpr (F8) {
         // 8-bit storage form: both column blocks' fragments are converted and written together (store_fragment_f8)
-        st.amax[SLOT] = (i == 0) ? f8_absmax(0u, w[j2]) : f8_absmax(st.amax[SLOT], w[j2]);
+        st.amax[SLOT] = f8_absmax<true>(i == 0 ? 0.f : st.amax[SLOT], v0, v1);
         if (i == 7) {
             char* tb = st.dys + (f8_offset_bytes(LOUT, st.P) + st.tile * F8_BLOCK_BYTES);
             char* sp = st.dys + (f8_scale_offset_bytes(LOUT, st.P) + st.tile * 64);

@@ -126,26 +126,50 @@ __device__ __forceinline__ void store_granule(__amdgpu_buffer_rsrc_t rs, int vof
 }
 
 // ---- 8-bit storage form (nerf_layout.h): one 32-feature fragment of the wave's 32 points -> e4m3 + its exponent ---------
-// Running maximum of the magnitudes of the packed bf16 pairs of a fragment (both column blocks): one AND + one packed
-// unsigned maximum per word -- a non-negative bf16 orders like its bit pattern.
-__device__ __forceinline__ unsigned f8_absmax(unsigned running, unsigned word) {
-    const u16x2 a = __builtin_bit_cast(u16x2, running), b = __builtin_bit_cast(u16x2, word & 0x7fff7fffu);
-    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(a, b));
+// Running maximum of the magnitudes that go into a fragment, taken on the fp32 values before they are packed: one
+// v_max3_f32 per packed pair (|.| is an operand modifier).  ABS = false is for ReLU outputs: max3(m, v0, v1) with m >= 0
+// is the maximum of the rectified values.  (A bf16 rounding may carry the largest value up to the next power of two: the
+// stored magnitude is then exactly 256 under the exponent chosen below -- e4m3 holds up to 448.)
+template <bool ABS>
+__device__ __forceinline__ float f8_absmax(float running, float v0, float v1) {
+    float r;
+    if constexpr (ABS) asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(running), "v"(v0), "v"(v1));
+    else asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(running), "v"(v0), "v"(v1));
+    return r;
 }
-template <int CTRL>
-__device__ __forceinline__ unsigned f8_max_dpp(unsigned v) {
-    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, false);
-    return o > v ? o : v;
+// The wave's maximum of a non-negative per-lane value, as the exponent field of lane 63's result: v_max_f32 with DPP
+// operands inside the 16-lane rows, then row_bcast 15 / 31, then one v_readlane.  Written as one asm block: a DPP
+// operand read needs two wait states behind the VALU write of that register, which the compiler cannot pad inside
+// inline asm (and its own expansion of the builtins costs a copy, a canonicalising maximum and the maximum per step).
+__device__ __forceinline__ int f8_wave_max_exponent(float m) {
+    int r;
+    asm volatile("s_nop 1\n\t"
+                 "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_readlane_b32 %0, %1, 63"
+                 : "=s"(r), "+v"(m));
+    return (r >> 23) & 0xff;
+}
+// two packed bf16 pairs -> four e4m3 bytes, each value divided by `scale` (a power of two) and rounded to nearest even
+__device__ __forceinline__ unsigned f8_cvt4(unsigned lo, unsigned hi, float scale) {
+    unsigned r;
+    asm("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %3\n\tv_cvt_scalef32_pk_fp8_bf16 %0, %2, %3 op_sel:[0,0,1]"
+        : "=&v"(r) : "v"(lo), "v"(hi), "s"(scale));
+    return r;
 }
 // w0 / w1: the fragment's four packed words of column block 0 / 1 (word j = features 32Q + 16 (j >> 1) + 4 g + 2 (j & 1)
-// + {0, 1} of the lane's point, g = lane >> 4); amax: f8_absmax over the eight words.  The wave agrees on the exponent of
-// its largest magnitude (DPP inside the 16-lane rows, four v_readlane across them), every pair is divided by
-// 2^(exponent - 7) and rounded to e4m3 by v_cvt_scalef32_pk_fp8_bf16 (round to nearest even; the largest value lands in
-// [128, 256), so nothing reaches e4m3's 448), and a 4 x 4 transpose of the lanes' four dwords across the lane groups
-// (two v_permlane32_swap + two v_permlane16_swap) leaves lane group g with ONE whole 16-byte granule: groups 0 / 1 =
-// chunks 2Q / 2Q+1 of points 0..15 of the wave, groups 2 / 3 the same chunks of points 16..31.  One dwordx4 store per
-// lane -- 512 contiguous bytes per chunk -- and one byte store of the exponent by lane 0: two vector-memory
-// instructions per fragment, as in the bf16 form (the counted waits of the chunk barrier do not change).
+// + {0, 1} of the lane's point, g = lane >> 4); amax: f8_absmax over the sixteen values.  The wave agrees on the exponent
+// of its largest magnitude (six DPP maxima: inside the 16-lane rows, then row_bcast 15 / 31, and one v_readlane), every
+// pair is divided by 2^(exponent - 7) and rounded to e4m3 by v_cvt_scalef32_pk_fp8_bf16 (round to nearest even; the
+// largest value lands in [128, 256], nothing reaches e4m3's 448), and a 4 x 4 transpose of the lanes' four dwords across
+// the lane groups (two v_permlane32_swap + two v_permlane16_swap) leaves lane group g with ONE whole 16-byte granule:
+// groups 0 / 1 = chunks 2Q / 2Q+1 of points 0..15 of the wave, groups 2 / 3 the same chunks of points 16..31.  One
+// dwordx4 store per lane -- 512 contiguous bytes per chunk -- and one byte store of the exponent by lane 0: two
+// vector-memory instructions per fragment, as in the bf16 form (the counted waits of the chunk barrier do not change).
 //   rs_data: the (layer, tile) block; voff = f8_lane_offset(lane, wave) or LOFF_INVALID; soff_data = Q * 8192.
 //   rs_scale: the tile's 64 exponent bytes of this layer; byte wave * 8 + Q is written.
 __host__ __device__ constexpr int f8_lane_offset(int lane, int wave) {
@@ -154,25 +178,15 @@ __host__ __device__ constexpr int f8_lane_offset(int lane, int wave) {
 template <int AUX = 0>
 __device__ __forceinline__ void store_fragment_f8(__amdgpu_buffer_rsrc_t rs_data, int voff, int soff_data,
                                                   __amdgpu_buffer_rsrc_t rs_scale, int lane, int scale_byte,
-                                                  u32x4 w0, u32x4 w1, unsigned amax) {
-    unsigned m = (amax >> 16) > (amax & 0xffffu) ? (amax >> 16) : (amax & 0xffffu);
-    m = f8_max_dpp<0xB1>(m);             // quad_perm [1,0,3,2]
-    m = f8_max_dpp<0x4E>(m);             // quad_perm [2,3,0,1]
-    m = f8_max_dpp<0x141>(m);            // row_half_mirror
-    m = f8_max_dpp<0x140>(m);            // row_mirror: every lane of a row holds the row's maximum
-    const unsigned r0 = __builtin_amdgcn_readlane(m, 0), r1 = __builtin_amdgcn_readlane(m, 16);
-    const unsigned r2 = __builtin_amdgcn_readlane(m, 32), r3 = __builtin_amdgcn_readlane(m, 48);
-    const unsigned r01 = r0 > r1 ? r0 : r1, r23 = r2 > r3 ? r2 : r3;
-    const int e = (int)((r01 > r23 ? r01 : r23) >> 7);            // biased exponent of the largest |bf16| (sign bit cleared)
+                                                  u32x4 w0, u32x4 w1, float amax) {
+    const int e = f8_wave_max_exponent(amax);                     // biased exponent of the wave's largest magnitude
     const int sb = e > 8 ? e - 7 : 1;                             // e8m0 byte of the block; >= 1 so the divisor is a normal float
     const float scale = __builtin_bit_cast(float, sb << 23);
-    s16x2 t = {0, 0};
-    auto cvt = [&](unsigned lo, unsigned hi) -> unsigned {
-        t = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(t, __builtin_bit_cast(bf16x2, lo), scale, false);
-        t = __builtin_amdgcn_cvt_scalef32_pk_fp8_bf16(t, __builtin_bit_cast(bf16x2, hi), scale, true);
-        return __builtin_bit_cast(unsigned, t);
-    };
-    const unsigned a0 = cvt(w0[0], w0[1]), b0 = cvt(w0[2], w0[3]), a1 = cvt(w1[0], w1[1]), b1 = cvt(w1[2], w1[3]);
+    const unsigned a0 = f8_cvt4(w0[0], w0[1], scale), b0 = f8_cvt4(w0[2], w0[3], scale);
+    unsigned a1 = f8_cvt4(w1[0], w1[1], scale), b1 = f8_cvt4(w1[2], w1[3], scale);
+    // v_permlane*_swap reads a VALU result two wait states behind its write; the conversions sit inside inline asm, where
+    // the compiler's hazard recogniser does not see them
+    asm volatile("s_nop 1" : "+v"(a1), "+v"(b1));
     // lane group g holds piece g of four granules (a0: chunk 2Q of its cb-0 point, b0: chunk 2Q+1, a1 / b1: the cb-1
     // point); after the transpose it holds pieces 0..3 of granule g
     const auto x0 = __builtin_amdgcn_permlane32_swap(a0, a1, false, false);
