@@ -869,8 +869,9 @@ def run_train(args):
         if e4m3:
             _lib.check(lib.nerf_amd_param_gradients_begin(_lib.ptr(stepper.d_raw), _lib.ptr(stepper.scratch), _lib.ptr(stepper.grads), P, st),
                        "nerf_amd_param_gradients_begin")
-            _lib.check(lib.nerf_amd_param_gradients_finish_e4m3(_lib.ptr(stepper.acts), _lib.ptr(stepper.dys), _lib.ptr(stepper.posx),
-                                                                _lib.ptr(stepper.posd), _lib.ptr(stepper.scratch), _lib.ptr(stepper.scratch8),
+            _lib.check(lib.nerf_amd_param_gradients_convert_e4m3(_lib.ptr(stepper.posx), _lib.ptr(stepper.posd), _lib.ptr(stepper.scratch),
+                                                                 _lib.ptr(stepper.scratch8), P, 3, st), "nerf_amd_param_gradients_convert_e4m3")
+            _lib.check(lib.nerf_amd_param_gradients_finish_e4m3(_lib.ptr(stepper.acts), _lib.ptr(stepper.dys), _lib.ptr(stepper.scratch8),
                                                                 _lib.ptr(stepper.grads), P, 0, st), "nerf_amd_param_gradients_finish_e4m3")
         else:
             _lib.check(lib.nerf_amd_param_gradients(_lib.ptr(stepper.d_raw), _lib.ptr(stepper.acts), _lib.ptr(stepper.dys),

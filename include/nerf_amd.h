@@ -322,18 +322,22 @@ int nerf_amd_param_gradients_finish_bucket(const void* acts, const void* dys, co
  * bytes (byte Q: features 32Q .. 32Q+31; value = e4m3 * 2^(byte - 127)); `acts` then carries the ReLU masks.
  *   nerf_amd_mlp_forward_train(..., flags | NERF_AMD_STORE_E4M3, ...)  with acts of nerf_amd_train_activation_bytes_e4m3(P)
  *   nerf_amd_mlp_backward_e4m3: dys of nerf_amd_train_gradient_bytes_e4m3(P)
- *   nerf_amd_param_gradients_begin (unchanged: packs d_raw into `scratch`), then
- *   nerf_amd_param_gradients_finish_e4m3: the 14 products on the block-scaled 8-bit MFMA; the bf16 encoder rows and the
- *   packed d_raw are converted into `scratch_e4m3` (nerf_amd_param_gradients_scratch_e4m3_bytes(P)) by the call
- *   (with buckets: by the call for bucket 0 or 1, which must come first). */
+ *   nerf_amd_param_gradients_begin (unchanged: packs d_raw into `scratch`);
+ *   nerf_amd_param_gradients_convert_e4m3: the narrow operands of the products into `scratch_e4m3`
+ *   (nerf_amd_param_gradients_scratch_e4m3_bytes(P)) -- which & 1: the bf16 encoder rows posx64 / posd32 (needs only
+ *   nerf_amd_sample_encode_bf16: a captured step runs it beside the forward), which & 2: the packed d_raw of `scratch`
+ *   (needs ..._begin: beside the dX chain);
+ *   nerf_amd_param_gradients_finish_e4m3: the 14 products on the block-scaled 8-bit MFMA and the bias sums (buckets as in
+ *   nerf_amd_param_gradients_finish_bucket). */
 #define NERF_AMD_STORE_E4M3 8u /* nerf_amd_mlp_forward_train only */
 int64_t nerf_amd_train_activation_bytes_e4m3(int64_t P);
 int64_t nerf_amd_train_gradient_bytes_e4m3(int64_t P);
 int64_t nerf_amd_param_gradients_scratch_e4m3_bytes(int64_t P);
 int nerf_amd_mlp_backward_e4m3(const float* d_raw, const void* bwd_image, const void* acts_e4m3,
                                void* dys_e4m3, int64_t P, void* stream);
-int nerf_amd_param_gradients_finish_e4m3(const void* acts_e4m3, const void* dys_e4m3, const void* posx64,
-                                         const void* posd32, const void* scratch, void* scratch_e4m3,
+int nerf_amd_param_gradients_convert_e4m3(const void* posx64, const void* posd32, const void* scratch,
+                                          void* scratch_e4m3, int64_t P, int which, void* stream);
+int nerf_amd_param_gradients_finish_e4m3(const void* acts_e4m3, const void* dys_e4m3, const void* scratch_e4m3,
                                          float* grads, int64_t P, int bucket, void* stream);
 
 /* ---- loss: nn.MSELoss(), reference train.py:42,52 -------------------------------- */

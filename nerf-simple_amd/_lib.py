@@ -76,7 +76,8 @@ _SIGNATURES = {
     "nerf_amd_train_gradient_bytes_e4m3": (_i64, [_i64]),
     "nerf_amd_param_gradients_scratch_e4m3_bytes": (_i64, [_i64]),
     "nerf_amd_mlp_backward_e4m3": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp]),
-    "nerf_amd_param_gradients_finish_e4m3": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_param_gradients_convert_e4m3": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "nerf_amd_param_gradients_finish_e4m3": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_sample_encode_bf16": (_i32, [_vp, _vp, _vp, _u32, _u64, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "nerf_amd_param_gradients_scratch_bytes": (_i64, [_i64]),
     "nerf_amd_param_gradients": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),

@@ -32,8 +32,8 @@ int nerf_amd_launch_mlp_f32(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_bf16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_f16_16(const MlpArgs*, int, hipStream_t);
 int nerf_amd_launch_mlp_backward(const float*, const void*, const void*, void*, long long, int, hipStream_t);
-int nerf_amd_launch_param_gradients_finish_e4m3(const void*, const void*, const void*, const void*, const void*, void*, float*,
-                                                long long, int, hipStream_t);
+int nerf_amd_launch_param_gradients_finish_e4m3(const void*, const void*, const void*, float*, long long, int, hipStream_t);
+int nerf_amd_launch_param_gradients_convert_e4m3(const void*, const void*, const void*, void*, long long, int, hipStream_t);
 long long nerf_amd_f8_scratch_bytes(long long);
 int nerf_amd_launch_mt19937_uniform(const uint32_t*, int, float*, long long, uint32_t*, hipStream_t);
 int nerf_amd_launch_mt19937_uniform_par(const uint32_t*, int, float*, long long, uint32_t*, const uint32_t*, int, long long,
@@ -512,13 +512,18 @@ int nerf_amd_mlp_backward_e4m3(const float* d_raw, const void* bwd_image, const 
     if (!d_raw || !bwd_image || !acts || !dys) return NERF_AMD_EINVAL;
     return nerf_amd_launch_mlp_backward(d_raw, bwd_image, acts, dys, P, 1, S(stream));
 }
-int nerf_amd_param_gradients_finish_e4m3(const void* acts, const void* dys, const void* posx64, const void* posd32,
-                                         const void* scratch, void* scratch_e4m3, float* grads, int64_t P, int bucket,
-                                         void* stream) {
+int nerf_amd_param_gradients_convert_e4m3(const void* posx64, const void* posd32, const void* scratch, void* scratch_e4m3,
+                                          int64_t P, int which, void* stream) {
+    if (P < 0 || which < 1 || which > 3) return NERF_AMD_EINVAL;
+    if (P == 0) return 0;
+    if (!scratch_e4m3 || ((which & 1) && (!posx64 || !posd32)) || ((which & 2) && !scratch)) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_param_gradients_convert_e4m3(posx64, posd32, scratch, scratch_e4m3, P, which, S(stream));
+}
+int nerf_amd_param_gradients_finish_e4m3(const void* acts, const void* dys, const void* scratch_e4m3, float* grads, int64_t P,
+                                         int bucket, void* stream) {
     if (P < 0 || !grads || bucket < 0 || bucket > 2) return NERF_AMD_EINVAL;
-    if (P > 0 && (!acts || !dys || !posx64 || !posd32 || !scratch || !scratch_e4m3)) return NERF_AMD_EINVAL;
-    return nerf_amd_launch_param_gradients_finish_e4m3(acts, dys, posx64, posd32, scratch, scratch_e4m3, grads, P, bucket,
-                                                       S(stream));
+    if (P > 0 && (!acts || !dys || !scratch_e4m3)) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_param_gradients_finish_e4m3(acts, dys, scratch_e4m3, grads, P, bucket, S(stream));
 }
 
 int nerf_amd_sample_encode_bf16(const float* rays, const float* u, const float* tbins, uint32_t flags,

@@ -309,15 +309,14 @@ extern "C" long long nerf_amd_f8_scratch_bytes(long long P) {
     return align256(f8_narrow_bytes(64, P)) + align256(f8_narrow_bytes(32, P)) + align256(f8_narrow_bytes(16, P));
 }
 
-// The 8-bit counterpart of nerf_amd_launch_param_gradients_finish: acts / dys in the 8-bit storage form, the row-major
-// bf16 encoder rows and the packed d_raw (`scratch`, written by ..._begin) converted here into `scratch_f8`.
-extern "C" int nerf_amd_launch_param_gradients_finish_e4m3(const void* acts_v, const void* dys_v, const void* posx64_v,
-                                                           const void* posd32_v, const void* scratch, void* scratch_f8,
-                                                           float* grads, long long P, int bucket, hipStream_t stream) {
+// The narrow operands of the products -- the row-major bf16 encoder rows (which & 1) and the packed d_raw that
+// nerf_amd_launch_param_gradients_begin leaves in `scratch` (which & 2) -- into `scratch_f8`.  Separate from the products so
+// that a captured step can run each conversion beside the kernel that does not need it (the encoder rows beside the
+// forward, d_raw beside the dX chain).
+extern "C" int nerf_amd_launch_param_gradients_convert_e4m3(const void* posx64_v, const void* posd32_v, const void* scratch,
+                                                            void* scratch_f8, long long P, int which, hipStream_t stream) {
     (void)hipGetLastError();
     if (P <= 0) return 0;
-    const char* acts = reinterpret_cast<const char*>(acts_v);
-    const char* dys = reinterpret_cast<const char*>(dys_v);
     char* px = reinterpret_cast<char*>(scratch_f8);
     char* pd = px + align256(f8_narrow_bytes(64, P));
     char* ds = pd + align256(f8_narrow_bytes(32, P));
@@ -328,13 +327,26 @@ extern "C" int nerf_amd_launch_param_gradients_finish_e4m3(const void* acts_v, c
                            reinterpret_cast<const __bf16*>(src), ld, W, P, dst,
                            reinterpret_cast<unsigned char*>(dst + f8_narrow_scale_offset(W, P)));
     };
-    if (bucket == 0 || bucket == 1) {
+    if (which & 1) {
         convert(posx64_v, 64, 64, px);
         convert(posd32_v, 32, 32, pd);
-        convert(scratch, 32, 16, ds);
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
+    if (which & 2) convert(scratch, 32, 16, ds);
+    return (int)hipGetLastError();
+}
+
+// The 8-bit counterpart of nerf_amd_launch_param_gradients_finish: acts / dys in the 8-bit storage form, the narrow operands
+// already converted (above).
+extern "C" int nerf_amd_launch_param_gradients_finish_e4m3(const void* acts_v, const void* dys_v, const void* scratch_f8,
+                                                           float* grads, long long P, int bucket, hipStream_t stream) {
+    (void)hipGetLastError();
+    if (P <= 0) return 0;
+    hipError_t e = hipSuccess;
+    const char* acts = reinterpret_cast<const char*>(acts_v);
+    const char* dys = reinterpret_cast<const char*>(dys_v);
+    const char* px = reinterpret_cast<const char*>(scratch_f8);
+    const char* pd = px + align256(f8_narrow_bytes(64, P));
+    const char* ds = pd + align256(f8_narrow_bytes(32, P));
 
     auto blocked = [&](const char* buf, int L) {
         return F8Operand{buf + f8_offset_bytes(L, P), reinterpret_cast<const unsigned char*>(buf + f8_scale_offset_bytes(L, P)),

@@ -537,6 +537,9 @@ class GraphedTrainStep:
         ck(lib.nerf_amd_sample_encode_bf16(ptr(self.rays), jit, ptr(self.tbins), flags, seed, rid,
                                            ptr(self.posx), ptr(self.posd), None, B, N_, ss),
            "nerf_amd_sample_encode_bf16")
+        if self._e4m3:       # the encoder rows in the products' 8-bit form: beside the forward as well
+            ck(lib.nerf_amd_param_gradients_convert_e4m3(ptr(self.posx), ptr(self.posd), None, ptr(self.scratch8), P, 1, ss),
+               "nerf_amd_param_gradients_convert_e4m3")
         ck(lib.nerf_amd_mlp_forward_train(ptr(self.rays), jit, ptr(self.tbins), ptr(packed),
                                           flags | (_lib.FLAG_STORE_E4M3 if self._e4m3 else 0), seed, rid,
                                           ptr(self.raw), ptr(self.ts), ptr(self.acts), B, N_, st),
@@ -548,6 +551,9 @@ class GraphedTrainStep:
         ck(lib.nerf_amd_mse_loss(ptr(self.rgb), ptr(self.gt), ptr(self.loss), None, B * 3, ss), "nerf_amd_mse_loss")
         ck(lib.nerf_amd_param_gradients_begin(ptr(self.d_raw), ptr(self.scratch), ptr(self.grads), P, ss),
            "nerf_amd_param_gradients_begin")
+        if self._e4m3:       # the packed d_raw likewise, beside the dX chain
+            ck(lib.nerf_amd_param_gradients_convert_e4m3(None, None, ptr(self.scratch), ptr(self.scratch8), P, 2, ss),
+               "nerf_amd_param_gradients_convert_e4m3")
         if self.rays_from is not None and self.device_rng:
             # rg.select + the colour gather (train.py:47-49) for the NEXT step, beside the dX chain: this step's rays and
             # colours have been read for the last time (encoder rows, forward, compositor, loss), and the selection depends
@@ -565,9 +571,8 @@ class GraphedTrainStep:
         """The dW products (all, or one bucket's) from the saved tensors in this step's storage form."""
         lib, ptr, P = _lib.lib(), _lib.ptr, self.B * self.N
         if self._e4m3:
-            _lib.check(lib.nerf_amd_param_gradients_finish_e4m3(ptr(self.acts), ptr(self.dys), ptr(self.posx), ptr(self.posd),
-                                                                ptr(self.scratch), ptr(self.scratch8), ptr(self.grads), P, bucket, st),
-                       "nerf_amd_param_gradients_finish_e4m3")
+            _lib.check(lib.nerf_amd_param_gradients_finish_e4m3(ptr(self.acts), ptr(self.dys), ptr(self.scratch8), ptr(self.grads),
+                                                                P, bucket, st), "nerf_amd_param_gradients_finish_e4m3")
         else:
             _lib.check(lib.nerf_amd_param_gradients_finish_bucket(ptr(self.acts), ptr(self.dys), ptr(self.posx), ptr(self.posd),
                                                                   ptr(self.scratch), ptr(self.grads), P, bucket, st),

@@ -107,8 +107,8 @@ def run_chain(dev, synthetic, B, N, e4m3, kind="default", seed=4):
     ck(lib.nerf_amd_param_gradients_begin(ptr(d_raw), ptr(scratch), ptr(grads), P, st), "begin")
     if e4m3:
         ck(lib.nerf_amd_mlp_backward_e4m3(ptr(d_raw), ptr(image), ptr(acts), ptr(dys), P, st), "backward")
-        ck(lib.nerf_amd_param_gradients_finish_e4m3(ptr(acts), ptr(dys), ptr(posx), ptr(posd), ptr(scratch), ptr(scratch8),
-                                                    ptr(grads), P, 0, st), "finish")
+        ck(lib.nerf_amd_param_gradients_convert_e4m3(ptr(posx), ptr(posd), ptr(scratch), ptr(scratch8), P, 3, st), "convert")
+        ck(lib.nerf_amd_param_gradients_finish_e4m3(ptr(acts), ptr(dys), ptr(scratch8), ptr(grads), P, 0, st), "finish")
     else:
         ck(lib.nerf_amd_mlp_backward(ptr(d_raw), ptr(image), ptr(acts), ptr(dys), P, st), "backward")
         ck(lib.nerf_amd_param_gradients_finish(ptr(acts), ptr(dys), ptr(posx), ptr(posd), ptr(scratch), ptr(grads), P, st), "finish")
@@ -173,7 +173,7 @@ def test_e4m3_buffers_are_the_bf16_ones_rounded(dev, synthetic, B, N):
             width = 128 if L == 9 else 256
             mean_rel = check_rounding(vals[L], raws[L], exps[L], ref[L], width, (name, L))
             assert mean_rel < 2.0 ** -5, (name, L, mean_rel)
-    # the encoder rows and the packed d_raw, converted inside the dW call
+    # the encoder rows and the packed d_raw (nerf_amd_param_gradients_convert_e4m3)
     from_rows = {64: a16["posx"], 32: a16["posd"],
                  16: bf16_to_f32(a16["scratch"][:P * 64].view(np.uint16).reshape(P, 32))[:, :16]}
     off = 0
