@@ -179,7 +179,11 @@ template <int AUX = 0>
 __device__ __forceinline__ void store_fragment_f8(__amdgpu_buffer_rsrc_t rs_data, int voff, int soff_data,
                                                   __amdgpu_buffer_rsrc_t rs_scale, int lane, int scale_byte,
                                                   u32x4 w0, u32x4 w1, float amax) {
+#if defined(F8_TIMING) && F8_TIMING == 1      // timing-only build (wrong exponents): what does the cross-lane chain cost?
+    const int e = (__builtin_bit_cast(int, amax) >> 23) & 0xff;
+#else
     const int e = f8_wave_max_exponent(amax);                     // biased exponent of the wave's largest magnitude
+#endif
     const int sb = e > 8 ? e - 7 : 1;                             // e8m0 byte of the block; >= 1 so the divisor is a normal float
     const float scale = __builtin_bit_cast(float, sb << 23);
     const unsigned a0 = f8_cvt4(w0[0], w0[1], scale), b0 = f8_cvt4(w0[2], w0[3], scale);
@@ -194,9 +198,17 @@ __device__ __forceinline__ void store_fragment_f8(__amdgpu_buffer_rsrc_t rs_data
     const auto y0 = __builtin_amdgcn_permlane16_swap(x0[0], x1[0], false, false);
     const auto y1 = __builtin_amdgcn_permlane16_swap(x0[1], x1[1], false, false);
     const unsigned o0 = y0[0], o1 = y0[1], o2 = y1[0], o3 = y1[1];
+#if defined(F8_TIMING) && F8_TIMING == 2      // timing-only build (nothing is stored): what do the stores cost?
+    asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(sb));
+#elif defined(F8_TIMING) && F8_TIMING == 3    // timing-only build: cached instead of non-temporal stores
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{o0, o1, o2, o3}, rs_data, voff, soff_data, 0);
+    asm volatile("s_nop 1" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
+    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_scale, lane == 0 ? scale_byte : LOFF_INVALID, 0, 0);
+#else
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{o0, o1, o2, o3}, rs_data, voff, soff_data, AUX);
     asm volatile("s_nop 1" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");      // store_granule's hazard
     __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_scale, lane == 0 ? scale_byte : LOFF_INVALID, 0, 0);
+#endif
 }
 
 template <int N>
