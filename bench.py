@@ -59,11 +59,10 @@ H = W = 800
 N_SAMPLES = 128
 TRAIN_RAYS, TRAIN_SAMPLES = 4096, 64   # per GPU (reference configs/lego.yaml:12; BASELINE config 5)
 DW_BYTES_PER_POINT = 11_776            # operands nerf_amd_param_gradients reads once per point
-DW_BYTES_PER_POINT_E4M3 = 5_856 + 368  # the same 15 products from 8-bit operands (d_raw rows 16 wide) + the conversion of the
-                                       # bf16 encoder rows and the packed d_raw (256 B read, 112 B written per point)
-# committed rocprofv3 PMC summaries (tools/profile_gpu.sh + tools/summarize_prof.py), newest first
+DW_BYTES_PER_POINT_E4M3 = 5_856         # the same 15 products from 8-bit operands (d_raw rows 16 wide instead of 32)
+
 PMC_SUMMARIES = [os.path.join(ROOT, "profiles", f) for f in
-                 ("r04_bench_fp16_pmc.json", "r04_train_pmc.json", "r03_bench_fp16_pmc.json", "r03_bench_bf16_pmc.json", "r03_train_pmc.json",
+                 ("r04_bench_fp16_pmc.json", "r04_train_pmc.json", "r04_train_e4m3_pmc.json", "r03_bench_fp16_pmc.json", "r03_bench_bf16_pmc.json", "r03_train_pmc.json",
                   "r02_bench_pmc.json", "r02e_train_pmc.json")]
 
 
@@ -932,7 +931,7 @@ def run_train(args):
                            "late-layer gradient launch to both reduced, collective_exposed_ms = the part behind the end of the "
                            "head-gradient launch that runs beside the first exchange") if multi else None,
             "roofline": {"bound": "hbm", "kernel": dw_kernel.rstrip("(") + " (timed: nerf_amd_param_gradients = zero fill + d_raw pack" +
-                                   (" + conversion of the narrow operands" if e4m3 else "") + " + the products)",
+                                   (" + conversion of the narrow operands (368 B per point, not in the algorithmic bytes)" if e4m3 else "") + " + the products)",
                          "achieved": achieved, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / PEAK_HBM,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": traffic_kind, "kernel_ms": dw_ms,
                          "algorithmic_bytes_per_point": dw_bytes,

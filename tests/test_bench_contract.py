@@ -1,4 +1,4 @@
-"""The bench contract, checked on the committed lines (profiles/r04_bench.json, profiles/r04_train_bench.json): every
+"""The bench contract, checked on the committed lines (profiles/r04c_bench.json, profiles/r04c_train_bench.json, r04c_train_e4m3_bench.json): every
 field the driver reads is there, the numbers are consistent with each other, and bench.py's own helpers (argument
 parsing, PMC lookup by full kernel instantiation) behave -- no GPU needed."""
 import importlib.util
@@ -31,7 +31,7 @@ def bench():
 
 
 def test_render_line():
-    d = load("r04_bench.json")
+    d = load("r04c_bench.json")
     for k in REQUIRED + ("cpu_baseline", "aux"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["higher_is_better"] is True and d["vs_baseline"] is None
@@ -66,6 +66,10 @@ def test_render_line():
     # the training iteration selects its batch from the 16 M-ray table inside the timed step
     for n in ("N64", "N128"):
         assert aux["c5"][n]["table_rays"] == 16_000_000 and "select_scan_kernel" in aux["c5"][n]["kernel"]
+        # ... and in the 8-bit storage form of the saved tensors, timed alike: faster, and the same training
+        e8 = aux["c5"][n]["storage_e4m3"]
+        assert e8["steps"] == aux["c5"][n]["steps"] and 0.6 * aux["c5"][n]["ms"] < e8["ms"] < 0.95 * aux["c5"][n]["ms"]
+        assert abs(e8["final_loss"] - aux["c5"][n]["final_loss"]) <= 0.02 * aux["c5"][n]["final_loss"]
     # rank 0 of 8 on the wall clock: kernel + collective + host gap = the step; eight such steps no slower than 1.33 full images
     s8 = aux["shard8"]
     assert "error" not in s8
@@ -74,8 +78,9 @@ def test_render_line():
     assert s8["train"]["step_ms_all_reduce"] >= s8["train"]["step_ms_no_exchange"] * 0.98
 
 
-def test_train_line():
-    d = load("r04_train_bench.json")
+@pytest.mark.parametrize("name,storage", [("r04c_train_bench.json", "bf16"), ("r04c_train_e4m3_bench.json", "e4m3")])
+def test_train_line(name, storage):
+    d = load(name)
     for k in REQUIRED:
         assert k in d, k
     assert d["scaling"] == "weak" and d["dtype"] == "bf16"
@@ -84,6 +89,15 @@ def test_train_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert d["config"]["table_rays"] == 16_000_000 and "rg.select" in d["config"]["batch"]
+    # the storage form of the saved tensors is named, its kernel is the one timed, and both forms are timed alike
+    assert ("e4m3" in d["config"]["storage"]) == (storage == "e4m3")
+    assert r["kernel"].startswith("dw_gemm_e4m3_kernel" if storage == "e4m3" else "dw_gemm_kernel")
+    assert r["algorithmic_bytes_per_point"] == (5856 if storage == "e4m3" else 11776)
+    assert r["traffic"] is None or 0.9 * r["algorithmic_bytes_per_point"] * P <= r["traffic"] <= 1.1 * r["algorithmic_bytes_per_point"] * P
+    by = d["by_storage"]
+    assert by[storage]["headline"] is True and by[storage]["ms_per_step"] == d["ms_per_step"]
+    assert by["e4m3"]["steps"] == by["bf16"]["steps"] and by["e4m3"]["ms_per_step"] < 0.9 * by["bf16"]["ms_per_step"]
+    assert abs(by["e4m3"]["final_loss"] - by["bf16"]["final_loss"]) <= 0.02 * by["bf16"]["final_loss"]
 
 
 def test_pmc_lookup_needs_the_exact_instantiation(bench):
@@ -98,3 +112,5 @@ def test_pmc_lookup_needs_the_exact_instantiation(bench):
     assert bench.pmc_traffic(bench.RENDER_KERNEL["fp32"], "render", "fp32") == (None, None)
     tt, _ = bench.pmc_traffic("dw_gemm_kernel(", "train")
     assert tt and tt > 2.5e9
+    t8, src8 = bench.pmc_traffic("dw_gemm_e4m3_kernel(", "train")
+    assert t8 and 1.3e9 < t8 < 1.7e9 and "e4m3" in src8
