@@ -516,8 +516,9 @@ class GraphedTrainStep:
     def _forward_backward(self, bucket=0):
         """Main branch: forward -> compositing + MSE gradient + compositing backward -> dX chain -> dW (all products,
         or with ``bucket`` = 1 only those of the late layers: _head_gradients adds the rest).
-        Side branch (a fork / join inside the captured graph): the encoder rows of the dW products
-        beside the forward, then loss value + gradient-vector zero fill + d_raw pack beside the dX chain."""
+        Side branch (ONE fork / join inside the captured graph, behind the compositor and beside the dX chain): the encoder
+        rows of the dW products, loss value, gradient-vector zero fill, d_raw pack, (8-bit form: the narrow operands'
+        conversion,) and the next step's batch selection."""
         lib, B, N_, P = _lib.lib(), self.B, self.N, self.B * self.N
         packed = self.net.packed_weights(_lib.BF16)
         image = self.net.packed_weights(_lib.BF16_BWD)
@@ -525,7 +526,6 @@ class GraphedTrainStep:
         main = torch.cuda.current_stream(self.dev)
         side = self._side
         st, ss = ctypes_stream(main), ctypes_stream(side)
-        side.wait_stream(main)
         if self.device_rng:
             # counter RNG; `u` = the address of this step's seed offset inside the hyper vector (int64 at float slot 6)
             import ctypes
@@ -533,13 +533,6 @@ class GraphedTrainStep:
             flags, seed, rid = _lib.FLAG_DEVICE_RNG | _lib.FLAG_SEED_IN_MEMORY, self.seed, self.ray_id0
         else:
             jit, flags, seed, rid = ptr(self.u), 0, 0, 0
-        # same sample positions as the forward draws them: ts = f(jitter) bit for bit (the same flags / u / seed / tbins)
-        ck(lib.nerf_amd_sample_encode_bf16(ptr(self.rays), jit, ptr(self.tbins), flags, seed, rid,
-                                           ptr(self.posx), ptr(self.posd), None, B, N_, ss),
-           "nerf_amd_sample_encode_bf16")
-        if self._e4m3:       # the encoder rows in the products' 8-bit form: beside the forward as well
-            ck(lib.nerf_amd_param_gradients_convert_e4m3(ptr(self.posx), ptr(self.posd), None, ptr(self.scratch8), P, 1, ss),
-               "nerf_amd_param_gradients_convert_e4m3")
         ck(lib.nerf_amd_mlp_forward_train(ptr(self.rays), jit, ptr(self.tbins), ptr(packed),
                                           flags | (_lib.FLAG_STORE_E4M3 if self._e4m3 else 0), seed, rid,
                                           ptr(self.raw), ptr(self.ts), ptr(self.acts), B, N_, st),
@@ -547,11 +540,26 @@ class GraphedTrainStep:
         # only rgb feeds the loss (train.py:52): disparity, alpha, acc, w are not materialised
         ck(lib.nerf_amd_volume_render_mse_backward(ptr(self.raw), ptr(self.ts), ptr(self.rays), ptr(self.gt), ptr(self.rgb),
                                                    ptr(self.d_raw), B, N_, st), "nerf_amd_volume_render_mse_backward")
-        side.wait_stream(main)
+        fork = torch.cuda.Event()
+        fork.record(main)                           # behind the compositor: what the side branch needs (rgb, d_raw) is final
+        backward = lib.nerf_amd_mlp_backward_e4m3 if self._e4m3 else lib.nerf_amd_mlp_backward
+        ck(backward(ptr(self.d_raw), ptr(image), ptr(self.acts), ptr(self.dys), P, st), "nerf_amd_mlp_backward")
+        side.wait_event(fork)
+        # The side branch carries everything the dW products need besides dY -- and nothing else runs beside the forward:
+        # a kernel enqueued next to a persistent kernel that fills every CU either delays its start (~10 us per branch at a
+        # replayed graph's root) or crawls beside it and slows the compositor behind it.  Order: the encoder rows read
+        # this step's rays and jitter, so they come before the selection overwrites the batch.
+        # same sample positions as the forward drew them: ts = f(jitter) bit for bit (the same flags / u / seed / tbins)
+        ck(lib.nerf_amd_sample_encode_bf16(ptr(self.rays), jit, ptr(self.tbins), flags, seed, rid,
+                                           ptr(self.posx), ptr(self.posd), None, B, N_, ss),
+           "nerf_amd_sample_encode_bf16")
+        if self._e4m3:       # the encoder rows in the products' 8-bit form
+            ck(lib.nerf_amd_param_gradients_convert_e4m3(ptr(self.posx), ptr(self.posd), None, ptr(self.scratch8), P, 1, ss),
+               "nerf_amd_param_gradients_convert_e4m3")
         ck(lib.nerf_amd_mse_loss(ptr(self.rgb), ptr(self.gt), ptr(self.loss), None, B * 3, ss), "nerf_amd_mse_loss")
         ck(lib.nerf_amd_param_gradients_begin(ptr(self.d_raw), ptr(self.scratch), ptr(self.grads), P, ss),
            "nerf_amd_param_gradients_begin")
-        if self._e4m3:       # the packed d_raw likewise, beside the dX chain
+        if self._e4m3:       # the packed d_raw likewise
             ck(lib.nerf_amd_param_gradients_convert_e4m3(None, None, ptr(self.scratch), ptr(self.scratch8), P, 2, ss),
                "nerf_amd_param_gradients_convert_e4m3")
         if self.rays_from is not None and self.device_rng:
@@ -562,8 +570,6 @@ class GraphedTrainStep:
             import ctypes
             self.rays_from.launch(self.select_mode, B, None, self._select_seed(1), ctypes.c_void_p(self.hyper.data_ptr() + 24),
                                   self.rays, self.gt, self._ids_next, stream=ss, workspace=self._select_ws)
-        backward = lib.nerf_amd_mlp_backward_e4m3 if self._e4m3 else lib.nerf_amd_mlp_backward
-        ck(backward(ptr(self.d_raw), ptr(image), ptr(self.acts), ptr(self.dys), P, st), "nerf_amd_mlp_backward")
         main.wait_stream(side)
         self._finish(bucket, st)
 

@@ -1,6 +1,7 @@
 """30 graphed training iterations with the reference's RNG stream (selection + jitter from torch's CPU generator, continued on
 the device), for a kernel trace:  rocprofv3 --kernel-trace --output-format csv -d OUT -- python3 tools/trace_ref_stream.py
-then  python3 tools/trace_ref_stream.py --analyse OUT  prints the timeline of one steady-state iteration."""
+then  python3 tools/trace_ref_stream.py --analyse OUT  prints the timeline of one steady-state iteration.
+(--counter: the counter-RNG form; --e4m3: the 8-bit storage form of the saved tensors.)"""
 import csv, glob, os, sys
 if len(sys.argv) > 2 and sys.argv[1] == "--analyse":
     rows = []
@@ -30,7 +31,8 @@ dev = torch.device("cuda:0")
 rg = bench.synthetic_ray_table(dev)
 net = Nerf(precision="bf16").to(dev)
 net.load_state_dict(synthetic.synthetic_state_dict(0, "default"))
-st = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), 4096, 64, rays_from=rg, device_rng="--counter" in sys.argv, seed=3)
+st = GraphedTrainStep(net, FusedAdam(net, lr=5e-4), 4096, 64, rays_from=rg, device_rng="--counter" in sys.argv, seed=3,
+                      storage="e4m3" if "--e4m3" in sys.argv else "bf16")
 torch.manual_seed(1)
 for _ in range(60):
     st.step()
