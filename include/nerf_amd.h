@@ -432,6 +432,15 @@ int nerf_amd_select_rays(const uint32_t* draws, uint64_t seed, const uint64_t* s
  * rewrites `hyper` (training.GraphedTrainStep). */
 int nerf_amd_adam_step_hyper(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                              int64_t n, const float* hyper, void* stream);
+/* The scalars of a captured step without a copy between graph launches: a ring of slots x 8 floats in PINNED HOST memory
+ * (one slot per step, written by the host before it launches the step: the 6 floats of `hyper` above, then whatever the
+ * caller keeps in floats 6..7 -- the training step's jitter seed offset as an int64).  nerf_amd_pinned_device_address
+ * returns the address under which the device reads such a buffer (hipHostGetDevicePointer; < 0: not pinned / not
+ * mapped) -- query it once, outside any capture; nerf_amd_hyper_fetch(ring_dev = that address, ...) copies slot
+ * (*counter % slots) into hyper[0..7] on the device and increments *counter (device memory, uint32).  The caller reuses
+ * a slot only after the step that read it has been passed by an event. */
+int64_t nerf_amd_pinned_device_address(const void* host);
+int nerf_amd_hyper_fetch(const float* ring_dev, int slots, float* hyper, uint32_t* counter, void* stream);
 
 /* ---- networks of other sizes: Nerf(Lp, Ld, H), reference utils/nets.py:9-32 ---------------- */
 /* The fused kernels implement the one configuration the reference constructs (Nerf() = (10, 4, 256): train.py:41,

@@ -87,6 +87,8 @@ _SIGNATURES = {
     "nerf_amd_mt19937_segments": (_i64, [_i32, _i64, _i64]),
     "nerf_amd_mt19937_uniform_par": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp, _i32, _i64, _vp, _vp]),
     "nerf_amd_adam_step_hyper": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "nerf_amd_hyper_fetch": (_i32, [_vp, _i32, _vp, _vp, _vp]),
+    "nerf_amd_pinned_device_address": (_i64, [_vp]),
     "nerf_amd_range_check": (_i32, [_vp, _vp, _vp, _vp, _u32, _u64, _i64, _vp, _i64, _i32, _vp]),
     "nerf_amd_mt19937_raw": (_i32, [_vp, _i32, _vp, _i64, _vp, _vp]),
     "nerf_amd_mt19937_jump_poly": (_i32, [_i64, _vp, _vp]),

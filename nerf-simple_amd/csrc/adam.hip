@@ -40,7 +40,24 @@ __global__ void adam_hyper_kernel(float* __restrict__ p, const float* __restrict
         p[i] -= (lr / bc1) * (mi / denom);
     }
 }
+// The step's scalars from a ring in pinned HOST memory (8 floats per slot, written by the host before it launches the
+// step) into the device vector the other kernels read, as a kernel: slot = *counter % slots, then *counter += 1.  A
+// replayed hipGraph can so begin with its own parameters' upload -- a stream-ordered hipMemcpyAsync between two graph
+// launches costs ~20 us of idle GPU at the seam (copy engine start + the launch behind it), a kernel node 2 us.
+__global__ void hyper_fetch_kernel(const float* ring, int slots, float* __restrict__ hyper, unsigned* __restrict__ counter) {
+    const unsigned c = *counter;
+    const float v = __builtin_nontemporal_load(ring + (size_t)(c % (unsigned)slots) * 8 + threadIdx.x);
+    __syncthreads();                       // every thread has read the counter
+    hyper[threadIdx.x] = v;
+    if (threadIdx.x == 0) *counter = c + 1;
+}
 }  // namespace
+
+extern "C" int nerf_amd_launch_hyper_fetch(const float* ring_host, int slots, float* hyper, unsigned* counter, hipStream_t stream) {
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(hyper_fetch_kernel, dim3(1), dim3(8), 0, stream, ring_host, slots, hyper, counter);
+    return (int)hipGetLastError();
+}
 
 extern "C" int nerf_amd_launch_adam_hyper(float* params, const float* grads, float* m, float* v, long long n,
                                           const float* hyper, hipStream_t stream) {

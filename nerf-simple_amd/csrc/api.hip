@@ -47,6 +47,7 @@ int nerf_amd_launch_select_rays(const uint32_t*, unsigned long long, const unsig
                                 const float*, float*, float*, long long*, void*, hipStream_t);
 int nerf_amd_host_mt19937_jump_poly(long long, const uint32_t*, uint32_t*);
 int nerf_amd_launch_adam_hyper(float*, const float*, float*, float*, long long, const float*, hipStream_t);
+int nerf_amd_launch_hyper_fetch(const float*, int, float*, unsigned*, hipStream_t);
 int nerf_amd_launch_linear_f32(const float*, long long, long long, const float*, const float*, long long, long long, const float*,
                                float*, long long, long long, long long, long long, int, hipStream_t);
 int nerf_amd_launch_adam(float*, const float*, float*, float*, long long, float, float, float, float, float, float,
@@ -651,6 +652,22 @@ int nerf_amd_linear_f32(const float* A, int64_t sa_i, int64_t sa_k, const float*
     if (M == 0 || N == 0) return 0;
     if (!C || ldc < N || (K > 0 && (!A || !B))) return NERF_AMD_EINVAL;
     return nerf_amd_launch_linear_f32(A, sa_i, sa_k, A_mask, B, sb_k, sb_j, bias, C, ldc, M, N, K, (int)flags, S(stream));
+}
+
+int64_t nerf_amd_pinned_device_address(const void* host) {
+    if (!host) return NERF_AMD_EINVAL;
+    (void)hipGetLastError();
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, const_cast<void*>(host), 0) != hipSuccess || !d) {
+        (void)hipGetLastError();
+        return NERF_AMD_EINVAL;                    // not pinned (or not mapped into the device's address space)
+    }
+    return (int64_t)reinterpret_cast<uintptr_t>(d);
+}
+
+int nerf_amd_hyper_fetch(const float* ring_dev, int slots, float* hyper, uint32_t* counter, void* stream) {
+    if (!ring_dev || !hyper || !counter || slots <= 0) return NERF_AMD_EINVAL;
+    return nerf_amd_launch_hyper_fetch(ring_dev, slots, hyper, counter, S(stream));
 }
 
 int nerf_amd_adam_step_hyper(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -310,29 +310,48 @@ def train_step(net, optimizer, rays, gt, N, *, tn=2, tf=6, u=None, decay=1.0, gr
 # the same step as ONE captured hipGraph (launch-bound at 4096-ray batches)
 # --------------------------------------------------------------------------
 class _HyperRing:
-    """Pinned host staging for the per-step Adam scalars.  The H2D copy of step k is asynchronous;
-    a single reused pinned buffer would be overwritten for step k+1 while step k's copy is still
-    queued on a GPU-bound stream (then Adam k runs with k+1's learning rate and bias corrections).
-    Each slot is reused only after the event recorded behind its own copy has completed."""
+    """Pinned host ring for the per-step scalars (Adam's six floats + the jitter seed offset as an int64): one slot per
+    step, written by the host before it launches the step and read on the device by the first node of graph A
+    (nerf_amd_hyper_fetch: slot = device counter % slots) -- no copy between two graph launches.  A slot is rewritten only
+    after the event recorded behind the launch that read it has completed; host index and device counter advance in
+    lockstep (``reset`` puts both back to 0)."""
 
-    def __init__(self, slots=8):
-        # 6 floats for Adam + one int64 (as two float slots): the jitter seed offset of the step (device_rng)
-        self.bufs = [torch.zeros(8, dtype=torch.float32).pin_memory() for _ in range(slots)]
+    def __init__(self, dev, slots=16):
+        self.ring = torch.zeros((slots, 8), dtype=torch.float32).pin_memory()
+        with torch.cuda.device(dev):
+            self.ring_dev = int(_lib.lib().nerf_amd_pinned_device_address(_lib.ptr(self.ring)))
+        if self.ring_dev <= 0:
+            raise RuntimeError("the pinned host ring of the step's scalars is not mapped into the device's address space")
+        self.counter = torch.zeros(1, dtype=torch.int32, device=dev)
         self.events = [None] * slots
         self.k = 0
 
-    def push(self, values, dst, seed_offset=0):
-        i = self.k % len(self.bufs)
-        self.k += 1
+    def reset(self):
+        self.k = 0
+        self.counter.zero_()
+
+    def push(self, values, seed_offset=0):
+        i = self.k % self.ring.shape[0]
         if self.events[i] is not None:
             self.events[i].synchronize()
-        h = self.bufs[i]
+            self.events[i] = None
+        h = self.ring[i]
         for j, v in enumerate(values):
             h[j] = v
         h[6:8].view(torch.int64)[0] = int(seed_offset)
-        dst.copy_(h, non_blocking=True)
+
+    def fetch(self, dst, dev):
+        """Enqueue (or capture) the device-side read of the next slot into ``dst``."""
+        import ctypes
+        _lib.check(_lib.lib().nerf_amd_hyper_fetch(ctypes.c_void_p(self.ring_dev), int(self.ring.shape[0]), _lib.ptr(dst), _lib.ptr(self.counter),
+                                                   _lib.stream_ptr(dev)), "nerf_amd_hyper_fetch")
+
+    def launched(self, dev):
+        """The launch that reads the slot just pushed is in the stream."""
+        i = self.k % self.ring.shape[0]
+        self.k += 1
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dst.device))
+        ev.record(torch.cuda.current_stream(dev))
         self.events[i] = ev
 
 
@@ -502,7 +521,7 @@ class GraphedTrainStep:
             _lib.check(lib.nerf_amd_grad_bucket_range(b, ctypes.byref(first), ctypes.byref(count)), "nerf_amd_grad_bucket_range")
             self.buckets.append(self.grads[first.value:first.value + count.value])
         self.hyper = torch.zeros(8, **f32)                 # [lr, b1, b2, eps, 1-b1^t, sqrt(1-b2^t), seed offset (int64)]
-        self._ring = _HyperRing()
+        self._ring = _HyperRing(dev)
         self._side = torch.cuda.Stream(dev)
         # parameters' .grad are views of the flat gradient vector, as after the eager fused backward
         off = 0
@@ -526,6 +545,8 @@ class GraphedTrainStep:
         main = torch.cuda.current_stream(self.dev)
         side = self._side
         st, ss = ctypes_stream(main), ctypes_stream(side)
+        # first node: this step's scalars (Adam's, the jitter seed offset) from the pinned host ring into `hyper`
+        self._ring.fetch(self.hyper, self.dev)
         if self.device_rng:
             # counter RNG; `u` = the address of this step's seed offset inside the hyper vector (int64 at float slot 6)
             import ctypes
@@ -623,7 +644,7 @@ class GraphedTrainStep:
         pg = self.opt.param_groups[0]
         b1, b2 = float(pg["betas"][0]), float(pg["betas"][1])
         self._ring.push((float(pg["lr"]), b1, b2, float(pg["eps"]), 1.0 - b1 ** step, (1.0 - b2 ** step) ** 0.5),
-                        self.hyper, seed_offset=step)
+                        seed_offset=step)
 
     def _capture(self):
         with torch.cuda.device(self.dev):
@@ -653,6 +674,7 @@ class GraphedTrainStep:
                 self._update()
             # capture executed nothing, and the warm-up did not touch the parameters
             assert torch.equal(self.opt.flat, params0)
+            self._ring.reset()                                   # the warm-up consumed a slot
             # a fresh pair of training images: whatever the warm-up left in their status words is gone
             self._own_images(force=True)
 
@@ -750,6 +772,7 @@ class GraphedTrainStep:
         self.opt.step_count += 1
         self._set_hyper(self.opt.step_count)
         self.graph_a.replay()
+        self._ring.launched(self.dev)
         if self.rays_from is not None and self.device_rng:
             self._primed_for = self.opt.step_count + 1          # graph A left the next step's batch in the buffers
         if self.check_every and self.opt.step_count % self.check_every == 0:
