@@ -672,6 +672,15 @@ class GraphedTrainStep:
             self.graph_b = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph_b):
                 self._update()
+            # Without an exchange nothing has to happen between the two on most steps: one graph for the whole iteration
+            # saves a launch seam (~5-10 us of idle GPU).  Steps that put a status copy / range check between forward and
+            # re-pack (check_every) replay the two separate graphs.
+            self.graph_ab = None
+            if not self.exchange:
+                self.graph_ab = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_ab):
+                    self._forward_backward(0)
+                    self._update()
             # capture executed nothing, and the warm-up did not touch the parameters
             assert torch.equal(self.opt.flat, params0)
             self._ring.reset()                                   # the warm-up consumed a slot
@@ -771,11 +780,13 @@ class GraphedTrainStep:
         from . import parallel
         self.opt.step_count += 1
         self._set_hyper(self.opt.step_count)
-        self.graph_a.replay()
+        watch = bool(self.check_every) and self.opt.step_count % self.check_every == 0
+        whole = self.graph_ab is not None and not watch
+        (self.graph_ab if whole else self.graph_a).replay()
         self._ring.launched(self.dev)
         if self.rays_from is not None and self.device_rng:
             self._primed_for = self.opt.step_count + 1          # graph A left the next step's batch in the buffers
-        if self.check_every and self.opt.step_count % self.check_every == 0:
+        if watch:
             # behind the forward, in front of graph B's re-pack (which clears the flag for the next step)
             self._watch.push(self._packed_fwd, self.opt.step_count)
             # the reference's |x| > 1 warning (utils/xyz.py:8-9) on the batch in the buffers (with the selection inside the
@@ -810,7 +821,8 @@ class GraphedTrainStep:
             if ev:
                 ev[1].record()
                 self._events.append([ev[0], ev[0], ev[1]])
-        self.graph_b.replay()
+        if not whole:
+            self.graph_b.replay()
         # graph B re-packed the two training images; any other image of the module (fp16 / fp32 inference) is now
         # stale -- and the kernels wrote through the flat buffer, so the parameters' versions did not move
         self.net.drop_packed(self.dev, keep=(_lib.BF16, _lib.BF16_BWD))
