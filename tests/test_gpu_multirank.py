@@ -151,7 +151,7 @@ def test_bench_self_launch_two_ranks(mode):
     assert res["ranks"]["backend"] == "gloo" and res["ranks"]["devices_distinct"] is False      # the rehearsal shares one GPU
 
 
-@pytest.mark.parametrize("mode", ["render", "train", "train2"])
+@pytest.mark.parametrize("mode", ["render", "train", "train2", "train2_e4m3"])
 def test_bench_rccl_single_rank_rehearsal(mode):
     """The multi-GPU step of bench.py over the REAL transport with the one GPU this box has: a process group of one rank
     on backend nccl (= RCCL), every collective issued all the same (NERF_BENCH_FORCE_DIST=1 ->
@@ -160,12 +160,13 @@ def test_bench_rccl_single_rank_rehearsal(mode):
     hipGraphs, all_gather_object in the self-check.  What it cannot show is the wire: more than one rank needs more than
     one GPU."""
     env = dict(os.environ, NERF_BENCH_FORCE_DIST="1", MASTER_PORT=str(free_port()),
-               NERF_BENCH_BUCKETS=("2" if mode == "train2" else "1"))
-    mode = "train" if mode == "train2" else mode
+               NERF_BENCH_BUCKETS=("2" if mode.startswith("train2") else "1"))
+    extra = ["--storage", "e4m3"] if mode.endswith("_e4m3") else []     # the 8-bit storage form through the bucketed launches
+    mode = "train" if mode.startswith("train2") else mode
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NERF_BENCH_BACKEND", "NERF_BENCH_SHARE_GPU"):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                        "--mode", mode, "--no-cpu-baseline", "--no-aux"], env=env, stdout=subprocess.PIPE,
+                        "--mode", mode, "--no-cpu-baseline", "--no-aux"] + extra, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=900)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]

@@ -68,7 +68,7 @@ def decode_e4m3_layers(host, P):
     return vals, raws, exps
 
 
-def run_chain(dev, synthetic, B, N, e4m3, kind="default", seed=4):
+def run_chain(dev, synthetic, B, N, e4m3, kind="default", seed=4, buckets=False):
     """Forward (saving), compositor backward, dX chain, dW through the C ABI in either storage form; returns the host
     copies of everything."""
     from nerf_simple_amd import _lib
@@ -108,7 +108,8 @@ def run_chain(dev, synthetic, B, N, e4m3, kind="default", seed=4):
     if e4m3:
         ck(lib.nerf_amd_mlp_backward_e4m3(ptr(d_raw), ptr(image), ptr(acts), ptr(dys), P, st), "backward")
         ck(lib.nerf_amd_param_gradients_convert_e4m3(ptr(posx), ptr(posd), ptr(scratch), ptr(scratch8), P, 3, st), "convert")
-        ck(lib.nerf_amd_param_gradients_finish_e4m3(ptr(acts), ptr(dys), ptr(scratch8), ptr(grads), P, 0, st), "finish")
+        for bucket in ((1, 2) if buckets else (0,)):              # the data-parallel step's two launches, or everything at once
+            ck(lib.nerf_amd_param_gradients_finish_e4m3(ptr(acts), ptr(dys), ptr(scratch8), ptr(grads), P, bucket, st), "finish")
     else:
         ck(lib.nerf_amd_mlp_backward(ptr(d_raw), ptr(image), ptr(acts), ptr(dys), P, st), "backward")
         ck(lib.nerf_amd_param_gradients_finish(ptr(acts), ptr(dys), ptr(posx), ptr(posd), ptr(scratch), ptr(grads), P, st), "finish")
@@ -253,6 +254,16 @@ def test_e4m3_products_add_nothing_of_their_own(dev, synthetic, B, N, kind):
         # fp32 accumulation over P <= 4096 points + float atomics of the split-K partials
         assert np.abs(got - w).max() <= 2e-5 * scale + 1e-12, (k, float(np.abs(got - w).max() / scale))
     assert off == a8["grads"].size and len(names) == 24
+
+
+def test_e4m3_buckets_are_the_whole(dev, synthetic):
+    """The two launches of the data-parallel step (bucket 1 = late layers, bucket 2 = layers_0.*) give the gradients of the one
+    launch: the same products, each workgroup share re-balanced per launch, so float atomics in another order."""
+    a, b = run_chain(dev, synthetic, 64, 64, True), run_chain(dev, synthetic, 64, 64, True, buckets=True)
+    assert np.array_equal(a["acts"], b["acts"]) and np.array_equal(a["dys"], b["dys"])
+    scale = np.abs(a["grads"]).max()
+    assert np.abs(a["grads"] - b["grads"]).max() <= 2e-5 * scale
+    assert np.count_nonzero(b["grads"]) > 0.9 * b["grads"].size
 
 
 def test_e4m3_against_bf16_gradients(dev, synthetic):

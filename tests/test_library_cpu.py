@@ -247,6 +247,23 @@ def test_abi_argument_errors(lib):
     assert lib.nerf_amd_mt19937_raw(null, 0, one, 4, null, null) == EINVAL
     assert lib.nerf_amd_mt19937_advance(one, one, one, null) == EINVAL                                          # in place
     assert lib.nerf_amd_mt19937_jump_poly(-1, one, one) == EINVAL
+    # the 8-bit storage form of the training step: sizes (10 layers x tiles x 64 KiB + 64 exponent bytes per layer and tile,
+    # acts: + the mask planes), flag accepted by the training forward only, conversions name what they convert
+    assert lib.nerf_amd_train_gradient_bytes_e4m3(1000) == 10 * 4 * (65536 + 64)
+    assert lib.nerf_amd_train_activation_bytes_e4m3(1000) == 10 * 4 * (65536 + 64) + 10 * 4 * 8192
+    assert lib.nerf_amd_train_activation_bytes_e4m3(-1) == EINVAL and lib.nerf_amd_param_gradients_scratch_e4m3_bytes(-1) == EINVAL
+    assert lib.nerf_amd_param_gradients_scratch_e4m3_bytes(1000) == 4 * (4 + 2 + 1) * 4096 + 3 * 4 * 64
+    assert lib.nerf_amd_render_forward(one, one, one, one, 1, 8 | 0, 0, 0, one, one, null, one, null, one, 4, 8, null) == EINVAL   # STORE_E4M3 elsewhere
+    assert lib.nerf_amd_mlp_forward_train(one, one, one, one, 8 | 16, 0, 0, one, one, one, 4, 8, null) == EINVAL                 # unknown bit beside it
+    assert lib.nerf_amd_mlp_backward_e4m3(one, one, null, one, 16, null) == EINVAL
+    assert lib.nerf_amd_param_gradients_convert_e4m3(one, one, one, one, 16, 0, null) == EINVAL                                 # nothing named
+    assert lib.nerf_amd_param_gradients_convert_e4m3(null, one, one, one, 16, 1, null) == EINVAL                                # encoder rows missing
+    assert lib.nerf_amd_param_gradients_convert_e4m3(null, null, null, one, 16, 2, null) == EINVAL                              # packed d_raw missing
+    assert lib.nerf_amd_param_gradients_convert_e4m3(null, null, null, null, 0, 3, null) == 0
+    assert lib.nerf_amd_param_gradients_finish_e4m3(one, one, one, one, 16, 3, null) == EINVAL
+    assert lib.nerf_amd_param_gradients_finish_e4m3(one, one, null, one, 16, 0, null) == EINVAL
+    assert lib.nerf_amd_hyper_fetch(null, 16, one, one, null) == EINVAL and lib.nerf_amd_hyper_fetch(one, 0, one, one, null) == EINVAL
+    assert lib.nerf_amd_pinned_device_address(null) == EINVAL
 
 
 def test_jump_polynomial_on_the_host(lib):
