@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nerf-simple_amd", "csrc")
 DEFAULT = [("mlp_bf16_16.hip", []), ("mlp_bf16_16.hip", ["-DNERF_HALF"]), ("mlp_f32.hip", []), ("mlp_bwd_16.hip", []),
-           ("dw_gemm.hip", []), ("composite.hip", [])]
+           ("dw_gemm.hip", []), ("dw_gemm_f8.hip", []), ("composite.hip", [])]
 FIELDS = (".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr_spill_count", ".group_segment_fixed_size",
           ".private_segment_fixed_size", ".max_flat_workgroup_size")
 
