@@ -1,4 +1,4 @@
-"""The bench contract, checked on the committed lines (profiles/r04c_bench.json, profiles/r04c_train_bench.json, r04c_train_e4m3_bench.json): every
+"""The bench contract, checked on the committed lines (profiles/r04d_bench.json, profiles/r04d_train_bench.json, r04d_train_e4m3_bench.json): every
 field the driver reads is there, the numbers are consistent with each other, and bench.py's own helpers (argument
 parsing, PMC lookup by full kernel instantiation) behave -- no GPU needed."""
 import importlib.util
@@ -31,7 +31,7 @@ def bench():
 
 
 def test_render_line():
-    d = load("r04c_bench.json")
+    d = load("r04d_bench.json")
     for k in REQUIRED + ("cpu_baseline", "aux"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["higher_is_better"] is True and d["vs_baseline"] is None
@@ -78,7 +78,7 @@ def test_render_line():
     assert s8["train"]["step_ms_all_reduce"] >= s8["train"]["step_ms_no_exchange"] * 0.98
 
 
-@pytest.mark.parametrize("name,storage", [("r04c_train_bench.json", "bf16"), ("r04c_train_e4m3_bench.json", "e4m3")])
+@pytest.mark.parametrize("name,storage", [("r04d_train_bench.json", "bf16"), ("r04d_train_e4m3_bench.json", "e4m3")])
 def test_train_line(name, storage):
     d = load(name)
     for k in REQUIRED:
