@@ -8,6 +8,10 @@
     python tests/studies/fuzz_gpu.py train      # 25 ragged (B, N) batches: fused training gradients vs the CPU oracle's
                                         # fp32 autograd under the test suite's stated bounds (tests/test_gpu_training.py)
 
+    python tests/studies/fuzz_gpu.py storage    # 60 random (B, N) batches through the 8-bit storage form of the training step
+                                        # (tests/test_gpu_storage.py's checks: every stored element = its bf16 value rounded
+                                        # to e4m3 under the block exponent; the products = float64 products of the decoded buffers)
+
 Uses oracle/ as the checker, like the tests.  Batches of a few points can exceed the per-tensor bound on the two sigma
 tensors: with similar colours along a ray d loss / d sigma is a difference of nearly equal terms, and bf16 colour noise
 of 1e-3 is then tens of per cent of it (2 x 3 points: 15 % of sum |d sigma_i|); it averages out with the batch
@@ -132,7 +136,53 @@ def select():
     print("select sweep done, mismatches:", bad)
 
 
+def storage():
+    import importlib.util
+    import numpy as np
+    import torch
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    spec = importlib.util.spec_from_file_location("storage_tests", os.path.join(ROOT, "tests", "test_gpu_storage.py"))
+    T = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(T)
+    from nerf_simple_amd.utils import synthetic
+    from nerf_simple_amd.utils.nets import Nerf
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    bad = 0
+    shapes = [(int(rng.integers(1, 400)), int(rng.integers(1, 40))) for _ in range(int(os.environ.get('FUZZ_BIG', '45')))] + \
+             [(int(rng.integers(1, 9)), int(rng.integers(1, 9))) for _ in range(15)]
+    for n, (B, N) in enumerate(shapes):
+        kind = ("default", "structured")[n % 2]
+        try:
+            a16 = T.run_chain(dev, synthetic, B, N, False, kind, seed=100 + n)
+            a8 = T.run_chain(dev, synthetic, B, N, True, kind, seed=100 + n)
+            P = a16["P"]
+            for k in ("raw", "ts", "d_raw"):
+                assert np.array_equal(a16[k], a8[k]), k
+            for name in ("acts", "dys"):
+                ref = T.decode_bf16_layers(a16[name], P)
+                vals, raws, exps = T.decode_e4m3_layers(a8[name], P)
+                for L in range(10):
+                    T.check_rounding(vals[L], raws[L], exps[L], ref[L], 128 if L == 9 else 256, (name, L))
+            want = T.expected_grads(a8, None)
+            off = 0
+            for k, p in Nerf().named_parameters():
+                m = p.numel()
+                got = a8["grads"][off:off + m].reshape(p.shape).astype(np.float64)
+                off += m
+                w = want[k].reshape(p.shape)
+                err, scale = np.abs(got - w).max(), max(np.abs(w).max(), 1e-30)
+                assert err <= 2.0 ** -11 * scale + 1e-12, f"{k}: error {err / scale:.3e} of the largest entry (bound 2^-11 = 4.9e-4)"
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH", B, N, kind, str(e)[:200])
+        if n % 10 == 9:
+            print(f"  {n + 1} / {len(shapes)} shapes", flush=True)
+    print("storage sweep done, mismatches:", bad)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) != 2 or sys.argv[1] not in ("render", "train", "select"):
+    if len(sys.argv) != 2 or sys.argv[1] not in ("render", "train", "select", "storage"):
         sys.exit(__doc__)
-    {"render": render, "train": train, "select": select}[sys.argv[1]]()
+    {"render": render, "train": train, "select": select, "storage": storage}[sys.argv[1]]()

@@ -9,8 +9,8 @@ Three layers of evidence, each through the C ABI:
      the subnormal range), the exponent puts the block's largest magnitude in [128, 256], and everything the chain itself
      produces (raw, ts, the ReLU masks) is bit for bit that of the bf16 form;
   2. the consumer: the 14 products and the bias sums from those very buffers equal the float64 products of the DECODED
-     operands to the accuracy of the instruction's inner sum (2^-13 of the tensor's largest entry; ~1e-5 over thousands of
-     points) -- the kernel adds no error of its own to what the storage form costs;
+     operands to the accuracy of the instruction's inner sum (2^-11 of the tensor's largest entry for a handful of points; ~1e-5 over
+     thousands) -- the kernel adds no error of its own to what the storage form costs;
   3. the requirement: at the reference's real step shape (fixture G6c, 4096 x 128) every gradient tensor stays inside
      GRAD_NOISE_RATIO of the reference's own minibatch deviation, and the 60-iteration trajectory inside the same bands as
      the bf16 form (tests/test_gpu_trajectory.py, modes with ``storage='e4m3'``).
@@ -254,9 +254,10 @@ def test_e4m3_products_add_nothing_of_their_own(dev, synthetic, B, N, kind):
         w = want[k].reshape(p.shape)
         scale = max(np.abs(w).max(), 1e-30)
         # fp32 accumulation + float atomics of the split-K partials, and the instruction's own inner sum: products 2^-14
-        # below the largest of their group of eight are dropped (tools/micro/f8_probe.hip) -- 2^-13 of the tensor's largest
-        # entry bounds it for a handful of points; over thousands the error is ~1e-5 (observed 2.4e-5 at P = 21)
-        assert np.abs(got - w).max() <= 2.0 ** -13 * scale + 1e-12, (k, float(np.abs(got - w).max() / scale))
+        # below the largest of their group of eight are dropped (tools/micro/f8_probe.hip): up to seven of them, 7 x 2^-14 <
+        # 2^-11 of the largest product -- that bounds it for a handful of points (observed up to 1.6e-4 at P = 16 on the
+        # high-gain weights); over thousands of points the error is ~1e-5
+        assert np.abs(got - w).max() <= 2.0 ** -11 * scale + 1e-12, (k, float(np.abs(got - w).max() / scale))
     assert off == a8["grads"].size and len(names) == 24
 
 
