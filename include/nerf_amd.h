@@ -319,7 +319,8 @@ int nerf_amd_param_gradients_finish_bucket(const void* acts, const void* dys, co
  * tests/test_gpu_storage.py against the reference's minibatch deviation).
  * Layout (csrc/nerf_layout.h): layer L at L * ceil(P/256) * 64 KiB, tile t at t * 64 KiB as
  * [feature/16 (16)][point in tile (256)][16 x e4m3]; behind the 10 layers, per layer and 32-point block 8 exponent
- * bytes (byte Q: features 32Q .. 32Q+31; value = e4m3 * 2^(byte - 127)); `acts` then carries the ReLU masks.
+ * bytes (byte Q: features 32Q .. 32Q+31; value = e4m3 * 2^(byte - 127); the producers choose one exponent per 128
+ * features, so bytes 4k .. 4k+3 are equal -- a consumer need not rely on it); `acts` then carries the ReLU masks.
  *   nerf_amd_mlp_forward_train(..., flags | NERF_AMD_STORE_E4M3, ...)  with acts of nerf_amd_train_activation_bytes_e4m3(P)
  *   nerf_amd_mlp_backward_e4m3: dys of nerf_amd_train_gradient_bytes_e4m3(P)
  *   nerf_amd_param_gradients_begin (unchanged: packs d_raw into `scratch`);

@@ -133,7 +133,7 @@ struct State {
     int loff[NCB];                    // block_lane_offset(lane>>4, point in tile): this lane's granule of
                                       // fragment 0 in the tile's activation block; LOFF_INVALID past the end
     unsigned mb[NCB][2];              // ReLU mask bits being collected [column block][pair group]
-    float amax[2];                    // 8-bit storage form: running maximum of the fragment being finished (f8_absmax)
+    float amax[4];                    // 8-bit storage form: running maximum of the fragment group being finished, by (layer, group) parity
     long long mask_tile;              // byte offset of this tile's dword 0 of layer 0 (nerf_layout::mask_offset_bytes), uniform
     // fused render only (COMP)
     long long p_end;                  // one past this workgroup's last point (uniform)
@@ -182,7 +182,7 @@ struct Stage {
 // 2Q, 2Q+1; both column blocks): piece i -> column block i>>2, word i&3 of the
 // next layer's fragment Q.  Heads: (L8, Q=8) is the lone sigma tile, L10 the
 // rgb tile.
-template <int L, int Q, int SAVE = 0, int SLOT = 0>
+template <int L, int Q, int SAVE = 0>
 __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2], ex8 (&dst)[NCB][8], State& st) {
     constexpr LayerDesc D = layer_desc(L);
     const int cb = i >> 2, j2 = i & 3;   // i in [0, 4*NCB)
@@ -202,18 +202,28 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
         w[j2] = pack2<D.relu != 0>(acc[cb][j2 >> 1][2 * (j2 & 1)], acc[cb][j2 >> 1][2 * (j2 & 1) + 1]);
         dst[cb][Q] = __builtin_bit_cast(ex8, w);
         if constexpr (SAVE == 2) {
-            // 8-bit storage form: magnitudes are collected word by word; when both column blocks' fragments are
-            // complete the wave converts and writes them together (nerf_device.h store_fragment_f8)
-            // (SLOT: the pending pair of the previous chunk and this chunk's first pair can be in flight together)
-            st.amax[SLOT] = f8_absmax<D.relu == 0>(i == 0 ? 0.f : st.amax[SLOT], acc[cb][j2 >> 1][2 * (j2 & 1)], acc[cb][j2 >> 1][2 * (j2 & 1) + 1]);
-            if (i == 4 * NCB - 1) {
-                static_assert(NCB == 2, "store_fragment_f8 takes the two column blocks of a wave");
-                char* tb = st.acts + (f8_offset_bytes(L, st.P) + st.tile * F8_BLOCK_BYTES);
-                char* sp = st.acts + (f8_scale_offset_bytes(L, st.P) + st.tile * 64);
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)F8_BLOCK_BYTES, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(sp, 0, 64, 0x00020000);
-                store_fragment_f8<2>(rs, st.loff[0], Q * 8192, rss, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6) * 8 + Q,
-                                     __builtin_bit_cast(u32x4, dst[0][Q]), w, st.amax[SLOT]);
+            // 8-bit storage form: magnitudes are collected word by word over a group of four fragments (128 features); when
+            // the group's last fragment is complete in both column blocks the wave converts and writes all four under one
+            // exponent (nerf_device.h store_group_f8).  The accumulator is picked by (layer, group) parity: the pending pair
+            // of the previous layer and this layer's first pair can be in flight together.
+            constexpr int GS = (L & 1) * 2 + ((Q >> 2) & 1);
+            st.amax[GS] = f8_absmax<D.relu == 0>(((Q & 3) == 0 && i == 0) ? 0.f : st.amax[GS], acc[cb][j2 >> 1][2 * (j2 & 1)],
+                                                 acc[cb][j2 >> 1][2 * (j2 & 1) + 1]);
+            if constexpr ((Q & 3) == 3) {
+                if (i == 4 * NCB - 1) {
+                    static_assert(NCB == 2, "store_group_f8 takes the two column blocks of a wave");
+                    constexpr int Q0 = Q - 3;
+                    char* tb = st.acts + (f8_offset_bytes(L, st.P) + st.tile * F8_BLOCK_BYTES);
+                    char* sp = st.acts + (f8_scale_offset_bytes(L, st.P) + st.tile * 64);
+                    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)F8_BLOCK_BYTES, 0x00020000);
+                    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(sp, 0, 64, 0x00020000);
+                    const u32x4 g0[4] = {__builtin_bit_cast(u32x4, dst[0][Q0]), __builtin_bit_cast(u32x4, dst[0][Q0 + 1]),
+                                         __builtin_bit_cast(u32x4, dst[0][Q0 + 2]), __builtin_bit_cast(u32x4, dst[0][Q0 + 3])};
+                    const u32x4 g1[4] = {__builtin_bit_cast(u32x4, dst[1][Q0]), __builtin_bit_cast(u32x4, dst[1][Q0 + 1]),
+                                         __builtin_bit_cast(u32x4, dst[1][Q0 + 2]), w};
+                    store_group_f8<2>(rs, st.loff[0], Q0 * 8192, rss, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6) * 8 + Q0,
+                                      g0, g1, st.amax[GS]);
+                }
             }
         }
         if constexpr (SAVE) {
@@ -257,7 +267,14 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[NCB][2]
 template <int SAVE>
 __host__ __device__ constexpr int pair_vmem_ops(int L, int Q) {
     if (!SAVE || L < 0 || L == 10 || (L == 8 && Q == 8)) return 0;
-    return NCB + ((layer_desc(L).relu != 0 && (Q & 3) == 3) ? NCB : 0);    // activations (+ a mask dword) per block
+    const int masks = (layer_desc(L).relu != 0 && (Q & 3) == 3) ? NCB : 0;  // a mask dword per block behind every fourth pair
+    // bf16 form: one activation store per block; 8-bit form: a group of four fragments at once (4 stores + 1 exponent dword)
+    return (SAVE == 2 ? ((Q & 3) == 3 ? F8_GROUP + 1 : 0) : NCB) + masks;
+}
+template <int SAVE>
+__host__ __device__ constexpr int pair_mask_ops(int L, int Q) {
+    if (!SAVE || L < 0 || L == 10 || (L == 8 && Q == 8)) return 0;
+    return (layer_desc(L).relu != 0 && (Q & 3) == 3) ? NCB : 0;
 }
 
 // the same summed over the pairs a chunk finishes itself (pairs P0 .. P0 + N - 1 of layer L)
@@ -271,21 +288,25 @@ template <int SAVE>
 __host__ __device__ constexpr int vmem_before_barrier(int L, int PL, int PQ, int pair0, int npair_in, int pend_m0, int pend_per,
                                                       int pair_m0, int mt, int m_limit) {
     int n = 0;
-    for (int cb = 0; cb < NCB; ++cb) {
-        // Column block cb's last piece (4 cb + 3) carries its mask dword and, in the bf16 form, its activation store; in
-        // the 8-bit form the wave's column blocks are converted and written together, by the pair's last piece (one
-        // data store + one exponent byte = NCB instructions: counted as one per column block, both at that piece).
-        const int own = 4 * cb + 3, data = SAVE == 2 ? 4 * NCB - 1 : own;
-        if (PL >= 0) {
-            const int ops = pair_vmem_ops<SAVE>(PL, PQ) / NCB;                    // 1, or 2 with a mask dword
-            if (ops > 0 && pend_m0 + data / pend_per < m_limit) n += 1;
-            if (ops > 1 && pend_m0 + own / pend_per < m_limit) n += ops - 1;
+    // Column block cb's last piece (4 cb + 3) carries its mask dword and, in the bf16 form, its activation store; in the
+    // 8-bit form the wave's column blocks are converted and written together -- a whole group of four fragments -- by
+    // the last piece of the group's last pair.
+    const int last = 4 * NCB - 1;
+    if (PL >= 0) {
+        const int masks = pair_mask_ops<SAVE>(PL, PQ), data = pair_vmem_ops<SAVE>(PL, PQ) - masks;
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int own = 4 * cb + 3;
+            if (pend_m0 + own / pend_per < m_limit) n += masks / NCB + (SAVE == 2 ? 0 : data / NCB);
         }
-        for (int j = 0; j < npair_in; ++j) {
-            const int ops = pair_vmem_ops<SAVE>(L, pair0 + j) / NCB;
-            if (ops > 0 && pair_m0 + j * 2 * mt + data < m_limit) n += 1;
-            if (ops > 1 && pair_m0 + j * 2 * mt + own < m_limit) n += ops - 1;
+        if (SAVE == 2 && pend_m0 + last / pend_per < m_limit) n += data;
+    }
+    for (int j = 0; j < npair_in; ++j) {
+        const int masks = pair_mask_ops<SAVE>(L, pair0 + j), data = pair_vmem_ops<SAVE>(L, pair0 + j) - masks;
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int own = 4 * cb + 3;
+            if (pair_m0 + j * 2 * mt + own < m_limit) n += masks / NCB + (SAVE == 2 ? 0 : data / NCB);
         }
+        if (SAVE == 2 && pair_m0 + j * 2 * mt + last < m_limit) n += data;
     }
     return n;
 }
@@ -424,8 +445,8 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[NC
 #pragma unroll
                         for (int k = 0; k < PEND_PER; ++k) {
                             const int i = (m - PEND_M0) * PEND_PER + k;
-                            if constexpr (PL == L) epilogue_piece<PL, PQ, SAVE, 1>(i, st.pend, out, st);
-                            else epilogue_piece<PL, PQ, SAVE, 1>(i, st.pend, in, st);
+                            if constexpr (PL == L) epilogue_piece<PL, PQ, SAVE>(i, st.pend, out, st);
+                            else epilogue_piece<PL, PQ, SAVE>(i, st.pend, in, st);
                         }
                     }
                 }

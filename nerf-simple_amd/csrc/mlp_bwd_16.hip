@@ -91,7 +91,7 @@ struct State {
     char* dys;
     long long P, tile;
     int loff[2];                    // block_lane_offset(lane>>4, point in tile), LOFF_INVALID past the end
-    float amax[2];                  // 8-bit storage form: running maximum of the fragment being finished (f8_absmax)
+    float amax[4];                  // 8-bit storage form: running maximum of the fragment group being finished, by (layer, group) parity
 };
 
 __device__ __forceinline__ unsigned pack2(float a, float b) {
@@ -124,7 +124,7 @@ __device__ __forceinline__ void load_mask(const State& st, u32x4& m) {
 
 // piece i of the epilogue of pair Q of backward layer B: mask, convert, and (on the
 // fragment's last word) store dY of forward layer 9-B
-template <int B, int Q, bool F8, int SLOT = 0>
+template <int B, int Q, bool F8>
 __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], ex8 (&dst)[2][8], State& st) {
     constexpr BwdDesc D = bwd_desc(B);
     constexpr int LOUT = 9 - B;
@@ -141,15 +141,24 @@ __device__ __forceinline__ void epilogue_piece(int i, const f32x4 (&acc)[2][2], 
     w[j2] = pack2(v0, v1);
     dst[cb][Q] = __builtin_bit_cast(ex8, w);
     if constexpr (F8) {
-        // 8-bit storage form: both column blocks' fragments are converted and written together (store_fragment_f8)
-        st.amax[SLOT] = f8_absmax<true>(i == 0 ? 0.f : st.amax[SLOT], v0, v1);
-        if (i == 7) {
-            char* tb = st.dys + (f8_offset_bytes(LOUT, st.P) + st.tile * F8_BLOCK_BYTES);
-            char* sp = st.dys + (f8_scale_offset_bytes(LOUT, st.P) + st.tile * 64);
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)F8_BLOCK_BYTES, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(sp, 0, 64, 0x00020000);
-            store_fragment_f8<2>(rs, st.loff[0], Q * 8192, rss, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6) * 8 + Q,
-                                 __builtin_bit_cast(u32x4, dst[0][Q]), w, st.amax[SLOT]);
+        // 8-bit storage form: a group of four fragments (both column blocks) is converted and written under one exponent
+        // when its last fragment is complete (nerf_device.h store_group_f8); accumulator by (layer, group) parity
+        constexpr int GS = (B & 1) * 2 + ((Q >> 2) & 1);
+        st.amax[GS] = f8_absmax<true>(((Q & 3) == 0 && i == 0) ? 0.f : st.amax[GS], v0, v1);
+        if constexpr ((Q & 3) == 3) {
+            if (i == 7) {
+                constexpr int Q0 = Q - 3;
+                char* tb = st.dys + (f8_offset_bytes(LOUT, st.P) + st.tile * F8_BLOCK_BYTES);
+                char* sp = st.dys + (f8_scale_offset_bytes(LOUT, st.P) + st.tile * 64);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(tb, 0, (int)F8_BLOCK_BYTES, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc(sp, 0, 64, 0x00020000);
+                const u32x4 g0[4] = {__builtin_bit_cast(u32x4, dst[0][Q0]), __builtin_bit_cast(u32x4, dst[0][Q0 + 1]),
+                                     __builtin_bit_cast(u32x4, dst[0][Q0 + 2]), __builtin_bit_cast(u32x4, dst[0][Q0 + 3])};
+                const u32x4 g1[4] = {__builtin_bit_cast(u32x4, dst[1][Q0]), __builtin_bit_cast(u32x4, dst[1][Q0 + 1]),
+                                     __builtin_bit_cast(u32x4, dst[1][Q0 + 2]), w};
+                store_group_f8<2>(rs, st.loff[0], Q0 * 8192, rss, (int)(threadIdx.x & 63), (int)(threadIdx.x >> 6) * 8 + Q0, g0, g1,
+                                  st.amax[GS]);
+            }
         }
     } else if (j2 == 3) {
         // one 16-byte granule per lane into the (layer, tile) block of dY, after trading 8-byte
@@ -229,8 +238,8 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
 #pragma unroll
                         for (int k = 0; k < PEND_PER; ++k) {
                             const int i = (m - PEND_M0) * PEND_PER + k;
-                            if constexpr (PB == B) epilogue_piece<PB, PQ, F8, 1>(i, st.pend, out, st);
-                            else epilogue_piece<PB, PQ, F8, 1>(i, st.pend, in, st);
+                            if constexpr (PB == B) epilogue_piece<PB, PQ, F8>(i, st.pend, out, st);
+                            else epilogue_piece<PB, PQ, F8>(i, st.pend, in, st);
                         }
                     }
                 }
@@ -257,7 +266,11 @@ __device__ __forceinline__ void chunk_step(const Ctx& c, State& st, ex8 (&in)[2]
     // this wave's LDS-DMA pieces (issued first in this chunk) have landed; what follows them may fly on:
     // 2 dY stores per finished pair (pending + this chunk's own) and the 4 mask loads of chunk 1
     constexpr bool PREFETCH = C == 1 && B + 1 < NUM_BWD && bwd_desc(B + 1 < NUM_BWD ? B + 1 : B).mask_act >= 0;
-    chunk_barrier<(PB >= 0 ? 2 : 0) + 2 + (PREFETCH ? 4 : 0)>();
+    // (8-bit form: a group of four fragments goes out with its last pair -- always an odd one, i.e. a pending pair: 4 data
+    // stores + 1 exponent dword; nothing otherwise)
+    constexpr int STORES = F8 ? ((PB >= 0 && (PQ & 3) == 3) ? F8_GROUP + 1 : 0) : (PB >= 0 ? 2 : 0) + 2;
+    static_assert(!F8 || ((2 * C) & 3) != 3, "an in-chunk pair never ends a group");
+    chunk_barrier<STORES + (PREFETCH ? 4 : 0)>();
 }
 
 __host__ __device__ constexpr int prev_layer(int b, int C) { return C > 0 ? b : b - 1; }

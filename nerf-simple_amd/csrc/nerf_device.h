@@ -125,7 +125,7 @@ __device__ __forceinline__ void store_granule(__amdgpu_buffer_rsrc_t rs, int vof
     asm volatile("s_nop 1" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
 }
 
-// ---- 8-bit storage form (nerf_layout.h): one 32-feature fragment of the wave's 32 points -> e4m3 + its exponent ---------
+// ---- 8-bit storage form (nerf_layout.h): fragments of the wave's 32 points -> e4m3 + the exponent of their group ---------
 // Running maximum of the magnitudes that go into a fragment, taken on the fp32 values before they are packed: one
 // v_max3_f32 per packed pair (|.| is an operand modifier).  ABS = false is for ReLU outputs: max3(m, v0, v1) with m >= 0
 // is the maximum of the rectified values.  (A bf16 rounding may carry the largest value up to the next power of two: the
@@ -161,31 +161,24 @@ __device__ __forceinline__ unsigned f8_cvt4(unsigned lo, unsigned hi, float scal
         : "=&v"(r) : "v"(lo), "v"(hi), "s"(scale));
     return r;
 }
-// w0 / w1: the fragment's four packed words of column block 0 / 1 (word j = features 32Q + 16 (j >> 1) + 4 g + 2 (j & 1)
-// + {0, 1} of the lane's point, g = lane >> 4); amax: f8_absmax over the sixteen values.  The wave agrees on the exponent
-// of its largest magnitude (six DPP maxima: inside the 16-lane rows, then row_bcast 15 / 31, and one v_readlane), every
-// pair is divided by 2^(exponent - 7) and rounded to e4m3 by v_cvt_scalef32_pk_fp8_bf16 (round to nearest even; the
-// largest value lands in [128, 256], nothing reaches e4m3's 448), and a 4 x 4 transpose of the lanes' four dwords across
-// the lane groups (two v_permlane32_swap + two v_permlane16_swap) leaves lane group g with ONE whole 16-byte granule:
-// groups 0 / 1 = chunks 2Q / 2Q+1 of points 0..15 of the wave, groups 2 / 3 the same chunks of points 16..31.  One
-// dwordx4 store per lane -- 512 contiguous bytes per chunk -- and one byte store of the exponent by lane 0: two
-// vector-memory instructions per fragment, as in the bf16 form (the counted waits of the chunk barrier do not change).
+// w0 / w1 below: a fragment's four packed words of column block 0 / 1 (word j = features 32Q + 16 (j >> 1) + 4 g + 2 (j & 1)
+// + {0, 1} of the lane's point, g = lane >> 4).  The wave agrees on the exponent of its largest magnitude (six DPP maxima:
+// inside the 16-lane rows, then row_bcast 15 / 31, and one v_readlane), every pair is divided by 2^(exponent - 7) and
+// rounded to e4m3 by v_cvt_scalef32_pk_fp8_bf16 (round to nearest even; the largest value lands in [128, 256], nothing
+// reaches e4m3's 448), and a 4 x 4 transpose of the lanes' four dwords across the lane groups (two v_permlane32_swap +
+// two v_permlane16_swap) leaves lane group g with ONE whole 16-byte granule: groups 0 / 1 = chunks 2Q / 2Q+1 of points
+// 0..15 of the wave, groups 2 / 3 the same chunks of points 16..31.  One dwordx4 store per lane: 512 contiguous bytes
+// per chunk.
 //   rs_data: the (layer, tile) block; voff = f8_lane_offset(lane, wave) or LOFF_INVALID; soff_data = Q * 8192.
-//   rs_scale: the tile's 64 exponent bytes of this layer; byte wave * 8 + Q is written.
+//   rs_scale: the tile's 64 exponent bytes of this layer.
 __host__ __device__ constexpr int f8_lane_offset(int lane, int wave) {
     return ((lane >> 4) & 1) * 4096 + (wave * 32 + 16 * (lane >> 5) + (lane & 15)) * 16;
 }
+// One fragment (32 features x the wave's 32 points) under an exponent already agreed on: eight conversions, the 4 x 4
+// transpose across the lane groups, one dwordx4 store per lane.
 template <int AUX = 0>
-__device__ __forceinline__ void store_fragment_f8(__amdgpu_buffer_rsrc_t rs_data, int voff, int soff_data,
-                                                  __amdgpu_buffer_rsrc_t rs_scale, int lane, int scale_byte,
-                                                  u32x4 w0, u32x4 w1, float amax) {
-#if defined(F8_TIMING) && F8_TIMING == 1      // timing-only build (wrong exponents): what does the cross-lane chain cost?
-    const int e = (__builtin_bit_cast(int, amax) >> 23) & 0xff;
-#else
-    const int e = f8_wave_max_exponent(amax);                     // biased exponent of the wave's largest magnitude
-#endif
-    const int sb = e > 8 ? e - 7 : 1;                             // e8m0 byte of the block; >= 1 so the divisor is a normal float
-    const float scale = __builtin_bit_cast(float, sb << 23);
+__device__ __forceinline__ void store_fragment_f8(__amdgpu_buffer_rsrc_t rs_data, int voff, int soff_data, u32x4 w0, u32x4 w1,
+                                                  float scale) {
     const unsigned a0 = f8_cvt4(w0[0], w0[1], scale), b0 = f8_cvt4(w0[2], w0[3], scale);
     unsigned a1 = f8_cvt4(w1[0], w1[1], scale), b1 = f8_cvt4(w1[2], w1[3], scale);
     // v_permlane*_swap reads a VALU result two wait states behind its write; the conversions sit inside inline asm, where
@@ -199,15 +192,38 @@ __device__ __forceinline__ void store_fragment_f8(__amdgpu_buffer_rsrc_t rs_data
     const auto y1 = __builtin_amdgcn_permlane16_swap(x0[1], x1[1], false, false);
     const unsigned o0 = y0[0], o1 = y0[1], o2 = y1[0], o3 = y1[1];
 #if defined(F8_TIMING) && F8_TIMING == 2      // timing-only build (nothing is stored): what do the stores cost?
-    asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(sb));
-#elif defined(F8_TIMING) && F8_TIMING == 3    // timing-only build: cached instead of non-temporal stores
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{o0, o1, o2, o3}, rs_data, voff, soff_data, 0);
-    asm volatile("s_nop 1" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");
-    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_scale, lane == 0 ? scale_byte : LOFF_INVALID, 0, 0);
+    asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3));
 #else
-    __builtin_amdgcn_raw_buffer_store_b128(u32x4{o0, o1, o2, o3}, rs_data, voff, soff_data, AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{o0, o1, o2, o3}, rs_data, voff, soff_data,
+#if defined(F8_TIMING) && F8_TIMING == 3    // timing-only build: cached instead of non-temporal stores
+                                           0);
+#else
+                                           AUX);
+#endif
     asm volatile("s_nop 1" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3) : "memory");      // store_granule's hazard
-    __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_scale, lane == 0 ? scale_byte : LOFF_INVALID, 0, 0);
+#endif
+}
+// A GROUP of four consecutive fragments (128 features x the wave's 32 points) under ONE exponent: the cross-lane step
+// (fourteen issue slots with its wait states) is paid once per four fragments -- these kernels are bound by vector-
+// instruction issue.  The four exponent bytes of the group (equal) go out as one dword by lane 0:
+// five vector-memory instructions per group.  w0[k] / w1[k]: fragment 4 (Q / 4) + k of column block 0 / 1; amax: f8_absmax over all
+// of them; soff_data: the group's first fragment (Q0 * 8192); scale_byte: wave * 8 + Q0 (a multiple of four).
+constexpr int F8_GROUP = 4;
+template <int AUX = 0>
+__device__ __forceinline__ void store_group_f8(__amdgpu_buffer_rsrc_t rs_data, int voff, int soff_data,
+                                               __amdgpu_buffer_rsrc_t rs_scale, int lane, int scale_byte,
+                                               const u32x4 (&w0)[F8_GROUP], const u32x4 (&w1)[F8_GROUP], float amax) {
+#if defined(F8_TIMING) && F8_TIMING == 1      // timing-only build (wrong exponents): what does the cross-lane chain cost?
+    const int e = (__builtin_bit_cast(int, amax) >> 23) & 0xff;
+#else
+    const int e = f8_wave_max_exponent(amax);                     // biased exponent of the wave's largest magnitude
+#endif
+    const int sb = e > 8 ? e - 7 : 1;                             // e8m0 byte of the block; >= 1 so the divisor is a normal float
+    const float scale = __builtin_bit_cast(float, sb << 23);
+#pragma unroll
+    for (int k = 0; k < F8_GROUP; ++k) store_fragment_f8<AUX>(rs_data, voff, soff_data + k * 8192, w0[k], w1[k], scale);
+#if !(defined(F8_TIMING) && F8_TIMING == 2)
+    __builtin_amdgcn_raw_buffer_store_b32((unsigned)sb * 0x01010101u, rs_scale, lane == 0 ? scale_byte : LOFF_INVALID, 0, 0);
 #endif
 }
 

@@ -265,7 +265,9 @@ NL_HD constexpr long long acts_total_bytes(long long P) { return acts_bf16_bytes
 //         the 32 points of a wave write 512 contiguous bytes per chunk, the dW kernel reads 64-point runs of 1 KiB;
 //   exponents: per layer, per 32-point block (one MLP wave) 8 bytes, byte Q = biased power-of-two exponent s (e8m0: the
 //         stored byte b means value = e4m3(b) * 2^(s - 127)) of features 32Q .. 32Q+31 -- the block scale of
-//         v_mfma_scale_f32_32x32x64_f8f6f4, chosen so that the largest magnitude lands in [128, 256);
+//         v_mfma_scale_f32_32x32x64_f8f6f4.  The MLP kernels choose ONE exponent per group of four such fragments (128
+//         features x 32 points; bytes 4k .. 4k+3 are equal) so that the group's largest magnitude lands in [128, 256]: the
+//         wave-wide maximum is paid once per group (nerf_device.h store_group_f8);
 //   (acts only) the ReLU masks, unchanged, behind them.
 // Narrow operands of the dW products (encoder rows, the packed d_raw) use the same form with their own chunk count.
 constexpr long long F8_BLOCK_BYTES = 256 * 256;

@@ -4,7 +4,8 @@ include/nerf_amd.h "8-bit storage form"; reference train.py:51-54: loss.backward
 Three layers of evidence, each through the C ABI:
 
   1. the producers: the buffers the training forward and the dX chain write with NERF_AMD_STORE_E4M3 decode (by the
-     documented layout, on the host) to the bf16 buffers of the default form rounded to e4m3 under the block's exponent --
+     documented layout, on the host) to the bf16 buffers of the default form rounded to e4m3 under the block's exponent (one
+     per group of four fragments = 128 features x 32 points) --
      element by element: |x8 - x16| <= half an e4m3 step at x16's magnitude (2^-4 relative; 2^-10 of the block scale in
      the subnormal range), the exponent puts the block's largest magnitude in [128, 256], and everything the chain itself
      produces (raw, ts, the ReLU masks) is bit for bit that of the bf16 form;
@@ -138,20 +139,26 @@ def check_rounding(v8, raw8, exps, v16, width, tag):
     err = np.abs(v8 - v16)
     assert (err <= tol * (1 + 1e-12)).all(), (tag, float((err / tol).max()))
     assert (np.sign(v8) * np.sign(v16) >= 0).all(), tag
-    # the exponent rule: the block's largest |bf16| lands in [128, 256) (blocks of zeros / of tiny values: byte 1)
+    # the exponent rule: ONE exponent per group of four fragments (128 features x 32 points: the producers pay the
+    # cross-lane step once per group), under which the group's largest |bf16| lands in [128, 256] (groups of zeros / of
+    # tiny values: byte 1)
     pad = (-P) % 32
     a = np.pad(np.abs(v16), ((0, pad), (0, 0))).reshape(-1, 32, nq, 32).max(axis=(1, 3))       # [block, Q]
     e = exps[:a.shape[0], :nq].astype(np.int64)
-    lead = a / 2.0 ** (e - 127.0)
+    ng = nq // 4
+    eg = e.reshape(-1, ng, 4)
+    assert (eg == eg[:, :, :1]).all(), tag                                                      # equal inside a group
+    ag = a.reshape(-1, ng, 4).max(axis=2)
+    lead = ag / 2.0 ** (eg[:, :, 0] - 127.0)
     # (the exponent comes from the fp32 values before their bf16 rounding, which can carry the largest one up to the next
     # power of two: exactly 256 then)
     assert (lead <= 256).all(), (tag, lead.max())
     # (a ragged last block: the wave's lanes past the end compute on the last point and take part in the maximum)
-    full = np.zeros(a.shape, dtype=bool)
+    full = np.zeros(ag.shape, dtype=bool)
     full[:P // 32] = True
-    big = full & (a >= 2.0 ** -118)
+    big = full & (ag >= 2.0 ** -118)
     assert (lead[big] >= 128).all(), (tag, lead[big].min())
-    assert (e[full & ~big] >= 1).all(), tag
+    assert (eg[:, :, 0][full & ~big] >= 1).all(), tag
     return float((err / np.maximum(np.abs(v16), 1e-30))[np.abs(v16) > 0].mean())
 
 
