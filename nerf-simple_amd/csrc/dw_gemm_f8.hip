@@ -17,7 +17,7 @@
 //   * fragments come out through ds_read_b64_tr_b8 (8 points x 16 features in, 8 consecutive points of one feature per
 //     lane out): four reads fill a lane's 32 bytes;
 //   * the exponents of the slab's two blocks (8 bytes each per operand) come by scalar loads;
-//   * db: column sums of the A slabs, each granule decoded with its block's scale (v_cvt_scalef32_pk_f32_fp8).
+//   * db = A^T . 1: one more MFMA per wave and slab against a fragment of ones.
 // HBM-bound by design at half the bytes of the bf16 form: (M + N) bytes per point and product.
 #include "nerf_device.h"
 
@@ -78,9 +78,16 @@ __device__ __forceinline__ void frags_landed(Frag (&a)[4], Frag (&b)[2]) {
 __device__ __forceinline__ i32x8 whole(const Frag& f) {
     return i32x8{f.q[0][0], f.q[0][1], f.q[1][0], f.q[1][1], f.q[2][0], f.q[2][1], f.q[3][0], f.q[3][1]};
 }
+// D = C in place (inline asm with a tied accumulator: with the builtin, sixteen-register accumulators that meet behind the
+// wave-uniform tile branches were copied -- 64 spilled registers once the bias tile's accumulator came in).  The operands
+// come from explicit waits (fragments) or from many instructions earlier (scales); the accumulators are read again one
+// slab later, or behind the s_nops that follow the loop.
 template <int OA, int OB>
-__device__ __forceinline__ f32x16 mfma(const Frag& a, const Frag& b, f32x16 c, int sa, int sb) {
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(whole(a), whole(b), c, 0, 0, OA, sa, OB, sb);
+__device__ __forceinline__ void mfma(const Frag& a, const Frag& b, f32x16& c, int sa, int sb) {
+    const i32x8 av = whole(a), bv = whole(b);
+    static_assert(OA >= 0 && OA < 4 && OB >= 0 && OB < 4, "op_sel picks one of four exponent bytes");
+    asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[%5,%6,0] op_sel_hi:[%7,%8,0]"
+                 : "+v"(c) : "v"(av), "v"(bv), "v"(sa), "v"(sb), "n"(OA & 1), "n"(OB & 1), "n"(OA >> 1), "n"(OB >> 1));
 }
 
 __global__ __launch_bounds__(512, 2) void dw_gemm_e4m3_kernel(GemmTableF8 tab) {
@@ -147,21 +154,34 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_e4m3_kernel(GemmTableF8 tab) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const bool active = m0 < M && n0 < N;
-    // tiles of this wave that exist (wave-uniform): the others' exponent bytes are never looked at
+    // tiles of this wave that exist (wave-uniform): the others' exponent bytes are never looked at (amask / bmask)
     bool ta[4], tb[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ta[i] = m0 + 32 * i < M;
+    for (int i = 0; i < 4; ++i) ta[i] = active && m0 + 32 * i < M;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) tb[j] = n0 + 32 * j < N;
+    for (int j = 0; j < 2; ++j) tb[j] = active && n0 + 32 * j < N;
+    // (the bias tile wn of a bias-only wave is among a's bytes too: its row tile exists whenever do_bias holds)
+    unsigned amask = 0, bmask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) amask |= (m0 + 32 * i < M) ? 0xffu << (8 * i) : 0u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) bmask |= (n0 + 32 * j < N) ? 0xffu << (8 * j) : 0u;
 
-    // db = column sums of the A slabs: thread -> chunk tid >> 5 (= features 16 (tid >> 5) .., exponent byte tid >> 6 = its
-    // wave), points (tid & 31) of either block
-    float bsum[16];
+    // db = column sums of A = A^T . 1: ONE more MFMA per wave and slab against a fragment of ones (e4m3 1.0, exponent
+    // 127).  Wave (wm, wn) takes row tile wn of its half: eight waves, eight row tiles, every row once.  (First version: two
+    // 16-byte LDS reads and 48 conversions / adds per thread and slab, then a reduction through LDS.  A timing-only build
+    // without them ran 12 % faster, but a same-box A/B of the two forms shows 1 %: 0.3074 -> 0.3042 ms for begin +
+    // conversions + products.  Kept for having no vector work and no second LDS pass, not for the time.)
+    const bool do_bias = d.bias && m0 + 32 * wn < M;
+    f32x16 accb;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) bsum[k] = 0.f;
-    const int brow = tid & 31, bchunk = tid >> 5;
-    const bool do_bias = d.bias && bchunk * 16 < M;
-    const unsigned baddr = (unsigned)(bchunk * CHS + brow * 16);
+    for (int r = 0; r < 16; ++r) accb[r] = 0.f;
+    const unsigned aoff_bias = (unsigned)(2 * (m0 / 32 + wn) * CHS) + lane_part;
+    Frag ab, ones;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ab.q[q] = i32x2{0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ones.q[q] = i32x2{0x38383838, 0x38383838};
 
     // exponents of the slab's two blocks: 16 contiguous bytes per operand
     auto load_scales = [&](long long s, u32x4& ea, u32x4& eb) {
@@ -188,65 +208,52 @@ __global__ __launch_bounds__(512, 2) void dw_gemm_e4m3_kernel(GemmTableF8 tab) {
         __builtin_amdgcn_s_barrier();              // slab s published; everyone is done with slab s-1
         if (s + RING - 1 < s_end) issue_slab(it + RING - 1, (it + RING - 1) & (RING - 1));     // into the slot of slab s-1
         // the scale registers of this slab: lanes 0..31 carry block 0's exponent, lanes 32..63 block 1's
-        const unsigned a_dw = h ? (wm ? ea[3] : ea[2]) : (wm ? ea[1] : ea[0]);
-        const unsigned b_dw = (h ? ((wn >> 1) ? eb[3] : eb[2]) : ((wn >> 1) ? eb[1] : eb[0])) >> (16 * (wn & 1));
+        const unsigned a_dw = (h ? (wm ? ea[3] : ea[2]) : (wm ? ea[1] : ea[0])) & amask;
+        const unsigned b_dw = ((h ? ((wn >> 1) ? eb[3] : eb[2]) : ((wn >> 1) ? eb[1] : eb[0])) >> (16 * (wn & 1))) & bmask;
         const u32x4 ea_now = ea;
         if (left >= 2) load_scales(s + 1, ea, eb);
 #if defined(F8_TIMING) && F8_TIMING == 4       // timing-only build: the LDS-DMA stream, its waits and barriers alone
         if (false) {
 #else
-        if (active) {
+        if (active || do_bias) {
 #endif
+            if (active) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) read_frag(a[i], base + aoff[i]);
+                for (int i = 0; i < 4; ++i) read_frag(a[i], base + aoff[i]);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) read_frag(b[j], base + boff[j]);
-            frags_landed(a, b);
-            __builtin_amdgcn_sched_barrier(0);
-            if (ta[0] && tb[0]) acc[0][0] = mfma<0, 0>(a[0], b[0], acc[0][0], (int)a_dw, (int)b_dw);
-            if (ta[0] && tb[1]) acc[0][1] = mfma<0, 1>(a[0], b[1], acc[0][1], (int)a_dw, (int)b_dw);
-            if (ta[1] && tb[0]) acc[1][0] = mfma<1, 0>(a[1], b[0], acc[1][0], (int)a_dw, (int)b_dw);
-            if (ta[1] && tb[1]) acc[1][1] = mfma<1, 1>(a[1], b[1], acc[1][1], (int)a_dw, (int)b_dw);
-            if (ta[2] && tb[0]) acc[2][0] = mfma<2, 0>(a[2], b[0], acc[2][0], (int)a_dw, (int)b_dw);
-            if (ta[2] && tb[1]) acc[2][1] = mfma<2, 1>(a[2], b[1], acc[2][1], (int)a_dw, (int)b_dw);
-            if (ta[3] && tb[0]) acc[3][0] = mfma<3, 0>(a[3], b[0], acc[3][0], (int)a_dw, (int)b_dw);
-            if (ta[3] && tb[1]) acc[3][1] = mfma<3, 1>(a[3], b[1], acc[3][1], (int)a_dw, (int)b_dw);
-        }
-        // (The bias sums cost the launch 12 %: 288 us as shipped, 254 without them, 248 for the DMA stream alone --
-        // timing-only builds F8_TIMING = 5 / 4, profiles/r04_f8_timing_variants.txt.  Requesting the granules with the
-        // fragments, or one dword's sums behind each MFMA, did not get it back: 291 / 300 us.)
-#if defined(F8_TIMING) && (F8_TIMING == 4 || F8_TIMING == 5)
-        if (false) {
-#else
-        if (do_bias) {
-#endif
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const u32x4 g = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(
-                    reinterpret_cast<lds_char*>(0) + base + baddr + blk * 512);
-                // exponent byte `wave` of block blk as a float 2^(e - 127)
-                const unsigned dw = (wave & 4) ? ea_now[2 * blk + 1] : ea_now[2 * blk];
-                const float sc = __builtin_bit_cast(float, ((dw >> (8 * (wave & 3))) & 0xffu) << 23);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const f32x2 lo = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(g[w], sc, false);
-                    const f32x2 hi = __builtin_amdgcn_cvt_scalef32_pk_f32_fp8(g[w], sc, true);
-                    bsum[4 * w + 0] += lo[0]; bsum[4 * w + 1] += lo[1]; bsum[4 * w + 2] += hi[0]; bsum[4 * w + 3] += hi[1];
-                }
+                for (int j = 0; j < 2; ++j) read_frag(b[j], base + boff[j]);
             }
+            // the bias tile's A fragment in registers of its own (row tile wn: a run-time index into a[] would be moves
+            // or four code paths with the 16-register accumulator merged behind them -- 64 spills)
+            if (do_bias) read_frag(ab, base + aoff_bias);
+            frags_landed(a, b);
+            asm volatile("" : "+v"(ab.q[0]), "+v"(ab.q[1]), "+v"(ab.q[2]), "+v"(ab.q[3]));     // (covered by the wait above)
+            __builtin_amdgcn_sched_barrier(0);
+            // (tiles past an operand's width are skipped; their exponent bytes are masked to 0 above all the same)
+            if (ta[0] && tb[0]) mfma<0, 0>(a[0], b[0], acc[0][0], (int)a_dw, (int)b_dw);
+            if (ta[0] && tb[1]) mfma<0, 1>(a[0], b[1], acc[0][1], (int)a_dw, (int)b_dw);
+            if (ta[1] && tb[0]) mfma<1, 0>(a[1], b[0], acc[1][0], (int)a_dw, (int)b_dw);
+            if (ta[1] && tb[1]) mfma<1, 1>(a[1], b[1], acc[1][1], (int)a_dw, (int)b_dw);
+            if (ta[2] && tb[0]) mfma<2, 0>(a[2], b[0], acc[2][0], (int)a_dw, (int)b_dw);
+            if (ta[2] && tb[1]) mfma<2, 1>(a[2], b[1], acc[2][1], (int)a_dw, (int)b_dw);
+            if (ta[3] && tb[0]) mfma<3, 0>(a[3], b[0], acc[3][0], (int)a_dw, (int)b_dw);
+            if (ta[3] && tb[1]) mfma<3, 1>(a[3], b[1], acc[3][1], (int)a_dw, (int)b_dw);
+#if !(defined(F8_TIMING) && F8_TIMING == 5)   // timing-only build: no bias sums
+            if (do_bias) {
+                constexpr int ONE = 0x7f7f7f7f;        // exponent byte 127 = 2^0 for the ones, whatever op_sel picks
+                mfma<0, 0>(ab, ones, accb, (int)(a_dw >> (8 * wn)), ONE);               // row tile wn's exponent into byte 0
+            }
+#endif
         }
     }
-    __syncthreads();
-    if (do_bias && s_begin < s_end) {
-        float* red = reinterpret_cast<float*>(smem);          // [32 rows][16 chunks][16]
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");      // the last MFMAs' results (inline asm: no hazard recogniser) before they are read
+    if (do_bias && s_begin < s_end && (lane & 31) == 0) {
+        // every column of the tile holds the row sums: column 0 (lanes 0 and 32) adds them into the flat vector
 #pragma unroll
-        for (int k = 0; k < 16; ++k) red[(brow * 16 + bchunk) * 16 + k] = bsum[k];
-    }
-    __syncthreads();
-    if (d.bias && s_begin < s_end && tid < M) {
-        float v = 0.f;
-        for (int r = 0; r < 32; ++r) v += reinterpret_cast<float*>(smem)[r * 256 + tid];
-        atomicAdd(d.bias + tid, v);
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + 32 * wn + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < M) atomicAdd(d.bias + row, accb[r]);
+        }
     }
     if (active && s_begin < s_end) {
 #pragma unroll
