@@ -857,25 +857,28 @@ def run_train(args):
         del ost, onet
     seen = ranks_seen(dist, dev, world)
     loss = float(stepper.loss)
-    # duration of the dominant kernel (dW + db, nerf_amd_param_gradients): 20 more launches on the same
-    # buffers right after the timed steps, bracketed by events on the launch stream
+    # duration of the dominant kernel (the dW products: nerf_amd_param_gradients_finish*): 20 more launches on the same
+    # buffers right after the timed steps, each bracketed by events on the launch stream.  What precedes it in a step -- the
+    # zero fill of the gradient vector and the d_raw pack (_begin; the 8-bit form: the conversion of the narrow operands) --
+    # is launched in front of the first event: the products add into the vector with atomics.
     st = _lib.stream_ptr(dev)
     image = net.packed_weights(_lib.BF16_BWD)
     evs = []
     for _ in range(20):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        _lib.check(lib.nerf_amd_param_gradients_begin(_lib.ptr(stepper.d_raw), _lib.ptr(stepper.scratch), _lib.ptr(stepper.grads), P, st),
+                   "nerf_amd_param_gradients_begin")
         if e4m3:
-            _lib.check(lib.nerf_amd_param_gradients_begin(_lib.ptr(stepper.d_raw), _lib.ptr(stepper.scratch), _lib.ptr(stepper.grads), P, st),
-                       "nerf_amd_param_gradients_begin")
             _lib.check(lib.nerf_amd_param_gradients_convert_e4m3(_lib.ptr(stepper.posx), _lib.ptr(stepper.posd), _lib.ptr(stepper.scratch),
                                                                  _lib.ptr(stepper.scratch8), P, 3, st), "nerf_amd_param_gradients_convert_e4m3")
+            e0.record()
             _lib.check(lib.nerf_amd_param_gradients_finish_e4m3(_lib.ptr(stepper.acts), _lib.ptr(stepper.dys), _lib.ptr(stepper.scratch8),
                                                                 _lib.ptr(stepper.grads), P, 0, st), "nerf_amd_param_gradients_finish_e4m3")
         else:
-            _lib.check(lib.nerf_amd_param_gradients(_lib.ptr(stepper.d_raw), _lib.ptr(stepper.acts), _lib.ptr(stepper.dys),
-                                                    _lib.ptr(stepper.posx), _lib.ptr(stepper.posd), _lib.ptr(stepper.scratch),
-                                                    _lib.ptr(stepper.grads), P, st), "nerf_amd_param_gradients")
+            e0.record()
+            _lib.check(lib.nerf_amd_param_gradients_finish(_lib.ptr(stepper.acts), _lib.ptr(stepper.dys), _lib.ptr(stepper.posx),
+                                                           _lib.ptr(stepper.posd), _lib.ptr(stepper.scratch), _lib.ptr(stepper.grads), P, st),
+                       "nerf_amd_param_gradients_finish")
         e1.record()
         evs.append((e0, e1))
     torch.cuda.synchronize(dev)
@@ -930,8 +933,8 @@ def run_train(args):
                            "two all-reduces of the flat gradient (1.27 MB, then 1.12 MB); collective_ms = from the end of the "
                            "late-layer gradient launch to both reduced, collective_exposed_ms = the part behind the end of the "
                            "head-gradient launch that runs beside the first exchange") if multi else None,
-            "roofline": {"bound": "hbm", "kernel": dw_kernel.rstrip("(") + " (timed: nerf_amd_param_gradients = zero fill + d_raw pack" +
-                                   (" + conversion of the narrow operands (368 B per point, not in the algorithmic bytes)" if e4m3 else "") + " + the products)",
+            "roofline": {"bound": "hbm", "kernel": dw_kernel.rstrip("(") + " (the one launch of nerf_amd_param_gradients_finish" +
+                                   ("_e4m3" if e4m3 else "") + ": all 14 products + the bias sums)",
                          "achieved": achieved, "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / PEAK_HBM,
                          "traffic": traffic, "traffic_source": traffic_src, "traffic_kind": traffic_kind, "kernel_ms": dw_ms,
                          "algorithmic_bytes_per_point": dw_bytes,
